@@ -1,0 +1,188 @@
+/*
+ * stmi.h -- C-ABI of libstmi355.so: gfx950 (MI355X) kernels for the
+ * style-transfer hot path of loveFeynman/style-transfer.
+ *
+ * The reference has no FFI of its own: every FLOP of its hot path runs inside
+ * TensorFlow ops called from Python.  Each entry point below replaces one such
+ * TensorFlow op call site (cited as reference file:line, paths relative to the
+ * reference's src/ directory) and is what a ctypes binding in the reference's
+ * Python would call instead.
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no C++ or torch types.
+ *   - every function returns 0 (STMI_OK) or a negative error code and leaves a
+ *     thread-local message readable through stmi_last_error().
+ *   - all tensor pointers are DEVICE pointers owned by the caller; activations
+ *     are NHWC, contiguous, in `dtype` (STMI_F32 or STMI_BF16) unless a
+ *     parameter is declared `float*`.
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and
+ *     never synchronise the device.  Functions are re-entrant.
+ *   - TensorFlow 'SAME' padding everywhere: out = ceil(in/stride),
+ *     pad_before = max((out-1)*stride + k - in, 0) / 2.
+ */
+#ifndef STMI_H
+#define STMI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STMI_OK 0
+#define STMI_ERR_INVALID (-1)
+#define STMI_ERR_HIP (-2)
+
+#define STMI_F32 0
+#define STMI_BF16 1
+
+#define STMI_ACT_NONE 0
+#define STMI_ACT_RELU 1
+#define STMI_ACT_SIGMOID 2
+
+/* which GEMM a packed weight buffer feeds */
+#define STMI_PACK_FWD 0   /* conv forward; transposed-conv backward-data */
+#define STMI_PACK_DGRAD 1 /* conv backward-data; transposed-conv forward */
+
+/* ---- library ---------------------------------------------------------- */
+int stmi_version(void);
+const char* stmi_last_error(void);
+/* writes e.g. "gfx950:sramecc+:xnack-" of the current device */
+int stmi_device_arch(char* buf, int buflen);
+
+/* ---- weight packing ---------------------------------------------------- */
+/* Weights live as fp32 HWIO [kh,kw,ci,co] (the layout of the reference's
+ * tf.Variable, model_utilities.py:236, and of the transposed .mat kernels,
+ * vgg.py:92-94).  The GEMM kernels read a K-contiguous, zero-padded copy in
+ * the compute dtype.  stmi_conv_packed_elems gives its size in elements. */
+long stmi_conv_packed_elems(int kh, int kw, int ci, int co, int mode);
+int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, int ci, int co,
+                           int mode, int dtype, void* stream);
+
+/* ---- convolution ------------------------------------------------------- */
+/* tf.nn.conv2d(x, W, [1,s,s,1], 'SAME')            (model_utilities.py:236-237)
+ * + tf.nn.bias_add                                 (model_utilities.py:163-164)
+ * + tf.nn.relu                                     (vgg.py:48, :98)
+ * x [n,h,w,ci] -> y [n,ceil(h/s),ceil(w/s),co].  bias may be NULL.  If y_pre is
+ * not NULL it receives the value before the ReLU (the pre-ReLU VGG taps of
+ * vgg.py:104-105). */
+int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
+                         int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                         int relu, int dtype, void* stream);
+
+/* Gradient of the above w.r.t. x (what tf.gradients emits as Conv2DBackpropInput
+ * for the ops at model_utilities.py:237 and :164):
+ *   dx = alpha * backprop_input(dy) ; dx = 0 where relu_mask <= 0 ; dx += addend.
+ * dy [n,ho,wo,co] -> dx [n,h,w,ci].  relu_mask and addend are optional tensors
+ * shaped like dx (addend may alias dx). */
+int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
+                           const void* relu_mask, const void* addend, float alpha,
+                           int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                           int dtype, void* stream);
+
+/* Gradient w.r.t. W (Conv2DBackpropFilter): dw fp32 [kh,kw,ci,co], overwritten. */
+int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw,
+                           int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                           int dtype, void* stream);
+
+/* tf.nn.conv2d_transpose(x, W, [n,s*h,s*w,co], [1,s,s,1], 'SAME') with
+ * W [kh,kw,co,ci]                                   (model_utilities.py:246-248)
+ * x [n,h,w,ci] -> y [n,s*h,s*w,co].  W is packed with STMI_PACK_DGRAD using
+ * (ci_pack, co_pack) = (co, ci): the op is the backward-data of a conv whose
+ * HWIO weight is W. */
+int stmi_conv2d_transpose_nhwc_fwd(const void* x, const void* w_packed_dgrad, void* y,
+                                   int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                   int dtype, void* stream);
+/* dy [n,s*h,s*w,co] -> dx [n,h,w,ci]; W packed with STMI_PACK_FWD, (ci_pack, co_pack) = (co, ci). */
+int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx,
+                                     const void* addend,
+                                     int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                     int dtype, void* stream);
+/* dw fp32 [kh,kw,co,ci], overwritten. */
+int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
+                                     int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                     int dtype, void* stream);
+
+/* ---- instance norm ----------------------------------------------------- */
+/* tf.nn.moments(x,[1,2]) ; scale*(x-mu)/(var+eps)**.5 + shift   (model_utilities.py:282-288)
+ * followed by the block's activation (model_utilities.py:240-241) and, for the
+ * second conv of a residual block, the skip add (model_utilities.py:278).
+ *
+ * stats  : per-(n,c) shifted partial sums -> ws (stmi_instance_norm_ws_floats floats)
+ * apply  : y = act(scale*xhat + shift) [+ residual]; optional fp32 copy y_f32;
+ *          writes mean/rstd pairs to stats_out [n,c,2] (fp32) when not NULL.
+ * bwd    : from dy (gradient w.r.t. y) to dx, and ADDS the parameter gradients
+ *          into dscale[c], dshift[c] (fp32).  The activation gradient is
+ *          recomputed from x, so y is not needed. */
+long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
+int stmi_instance_norm_nhwc_stats(const void* x, float* ws, int n, int h, int w, int c,
+                                  int dtype, void* stream);
+int stmi_instance_norm_nhwc_apply(const void* x, const float* ws, const float* scale, const float* shift,
+                                  const void* residual, void* y, float* y_f32, float* stats_out,
+                                  float eps, int act, int n, int h, int w, int c,
+                                  int dtype, void* stream);
+int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats,
+                                const float* scale, const float* shift,
+                                void* dx, float* dscale, float* dshift, float* ws,
+                                float eps, int act, int n, int h, int w, int c,
+                                int dtype, void* stream);
+
+/* ---- VGG pieces -------------------------------------------------------- */
+/* x*255/2 - mean                                    (vgg.py:11-17)
+ * x fp32 [count/c, c] -> y in dtype; y = x*scale - mean[c]. */
+int stmi_scale_shift(const float* x, const float* mean, void* y, float scale, long count, int c,
+                     int dtype, void* stream);
+/* tf.nn.max_pool2d(2,2,'SAME')                      (model_utilities.py:166-167)
+ * x [n,h,w,c] -> y [n,ceil(h/2),ceil(w/2),c] */
+int stmi_maxpool2x2_same_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream);
+/* MaxPoolGrad fused with the ReLU gradient of the layer that fed the pool:
+ * dx = dy routed to the first maximum of each window, zero where x <= 0
+ * (x is the post-ReLU pool input). */
+int stmi_maxpool2x2_same_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c,
+                             int dtype, void* stream);
+
+/* ---- Gram matrix ------------------------------------------------------- */
+/* tf.linalg.einsum('bijc,bijd->bcd', F, F) / (H*W)   (model_utilities.py:380-384)
+ * f [n,h,w,c] -> g fp32 [n,c,c], overwritten. */
+int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream);
+/* df[p][c] (+)= sum_d F[p][d] * S[b][c][d], S = (dG + dG^T)/(H*W) in dtype, in the
+ * zero-padded K-contiguous layout stmi_gram_mse_fwd_bwd writes
+ * (stmi_gram_packed_elems elements).  accumulate != 0 adds into df.  c % 8 == 0. */
+long stmi_gram_packed_elems(int n, int c);
+int stmi_gram_nhwc_bwd(const void* f, const void* s, void* df, int accumulate,
+                       int n, int h, int w, int c, int dtype, void* stream);
+
+/* ---- losses ------------------------------------------------------------ */
+/* tf.reduce_mean((a-b)**2) terms of sum_mse          (model_utilities.py:387-388)
+ * All three ADD loss_scale * sum((a-b)^2) into loss[0] (fp32, device) and emit
+ * grad_scale * (a-b).
+ * gram form: g fp32 [n,c,c], target fp32 [c,c] broadcast over n; s_out in dtype,
+ * stmi_gram_packed_elems(n,c) elements. */
+int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* loss,
+                          float loss_scale, float grad_scale, int n, int c, int dtype, void* stream);
+int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* loss,
+                     float loss_scale, float grad_scale, long count, int dtype, void* stream);
+/* total_variation_loss                               (model_utilities.py:369-377)
+ * img fp32 [n,h,w,c]; loss[0] += weight*(mean(dx^2)+mean(dy^2)); grad (dtype) =
+ * weight * d/d img, overwritten. */
+int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight,
+                         int n, int h, int w, int c, int dtype, void* stream);
+
+/* ---- optimizer --------------------------------------------------------- */
+/* tf.train.AdamOptimizer update (call sites full_graph_stylizer_network.py:125, :278):
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).
+ * step_dev (device int32) is incremented first and gives t; pass NULL to use
+ * the host value t instead.  grad_scale multiplies g first (1/world for
+ * data-parallel sums). */
+int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count,
+                  float lr, float beta1, float beta2, float eps, float grad_scale,
+                  int* step_dev, int t, void* stream);
+
+/* ---- small utilities --------------------------------------------------- */
+/* dtype conversion between fp32 and `dtype`; to_f32 != 0 converts dtype -> fp32 */
+int stmi_cast(const void* src, void* dst, long count, int dtype, int to_f32, void* stream);
+/* tf.clip_by_value(x, lo, hi) in place, fp32           (model_utilities.py:365-366) */
+int stmi_clip(float* x, long count, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STMI_H */

@@ -1,0 +1,267 @@
+// extern "C" surface of libstmi355.so (declared in include/stmi.h).
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace stmi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return STMI_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return STMI_ERR_HIP;
+}
+
+// implemented in the kernel translation units
+int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
+int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
+                  int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s);
+int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
+                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
+int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
+                    int stride, int dtype, hipStream_t s);
+int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s);
+int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
+                  hipStream_t s);
+long in_ws_floats(int n, int h, int w, int c);
+int in_stats_impl(const void* x, float* ws, int n, int h, int w, int c, int dtype, hipStream_t s);
+int in_apply_impl(const void* x, const float* ws, const float* scale, const float* shift, const void* residual,
+                  void* y, float* y_f32, float* stats_out, float eps, int act, int n, int h, int w, int c, int dtype,
+                  hipStream_t s);
+int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
+                float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
+int scale_shift_impl(const float*, const float*, void*, float, long, int, int, hipStream_t);
+int cast_impl(const void*, void*, long, int, int, hipStream_t);
+int clip_impl(float*, long, float, float, hipStream_t);
+int pool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
+int pool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
+int mse_impl(const void*, const void*, void*, float*, float, float, long, int, hipStream_t);
+int gram_mse_impl(const float*, const float*, void*, float*, float, float, int, int, int, hipStream_t);
+int tv_impl(const float*, void*, float*, float, int, int, int, int, int, hipStream_t);
+int adam_impl(float*, const float*, float*, float*, long, float, float, float, float, float, int*, int, hipStream_t);
+
+static int check_dtype(int dtype) {
+    if (dtype == STMI_F32 || dtype == STMI_BF16) return STMI_OK;
+    set_error("unknown dtype %d", dtype);
+    return STMI_ERR_INVALID;
+}
+
+static int check_conv(const char* who, int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    if (n < 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || kh > 9 || kw > 9) {
+        set_error("%s: bad geometry n=%d h=%d w=%d ci=%d co=%d k=%dx%d stride=%d", who, n, h, w, ci, co, kh, kw, stride);
+        return STMI_ERR_INVALID;
+    }
+    return STMI_OK;
+}
+
+}  // namespace stmi
+
+using namespace stmi;
+
+#define S(stream) ((hipStream_t)(stream))
+
+extern "C" {
+
+int stmi_version(void) { return 100; }
+
+const char* stmi_last_error(void) { return g_err; }
+
+int stmi_device_arch(char* buf, int buflen) {
+    int dev = 0;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    rc = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    if (rc) return rc;
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return STMI_OK;
+}
+
+long stmi_conv_packed_elems(int kh, int kw, int ci, int co, int mode) {
+    const PackGeom g = pack_geom(kh, kw, ci, co, mode);
+    return (long)g.ntaps * g.rows_pad * g.kpad;
+}
+
+int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, int ci, int co, int mode, int dtype,
+                           void* stream) {
+    if (check_conv("pack_conv_weights", 0, 1, 1, ci, co, kh, kw, 1, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(mode == STMI_PACK_FWD || mode == STMI_PACK_DGRAD, "pack_conv_weights: bad mode %d", mode);
+    STMI_REQUIRE(w_hwio && packed, "pack_conv_weights: null pointer");
+    return pack_weights_impl(w_hwio, packed, kh, kw, ci, co, mode, dtype, S(stream));
+}
+
+int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre, int n,
+                         int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_fwd", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_fwd && y, "conv2d_nhwc_fwd: null pointer");
+    return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream));
+}
+
+int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,
+                           const void* addend, float alpha, int n, int h, int w, int ci, int co, int kh, int kw,
+                           int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_dgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(dy && w_packed_dgrad && dx, "conv2d_nhwc_dgrad: null pointer");
+    return conv_dgrad_impl(dy, w_packed_dgrad, dx, relu_mask, addend, alpha, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
+}
+
+int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh,
+                           int kw, int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && dy && dw, "conv2d_nhwc_wgrad: null pointer");
+    return conv_wgrad_impl(x, dy, dw, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
+}
+
+// A transposed conv x[n,h,w,ci] -> y[n,sh,sw,co] with W[kh,kw,co,ci] is the backward-data of the
+// conv (n, sh, sw, co) -> ci whose HWIO weight is W.
+int stmi_conv2d_transpose_nhwc_fwd(const void* x, const void* w_packed_dgrad, void* y, int n, int h, int w, int ci,
+                                   int co, int kh, int kw, int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_transpose_nhwc_fwd", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_dgrad && y, "conv2d_transpose_nhwc_fwd: null pointer");
+    return conv_dgrad_impl(x, w_packed_dgrad, y, nullptr, nullptr, 1.f, n, h * stride, w * stride, co, ci, kh, kw, stride, dtype, S(stream));
+}
+
+int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx, const void* addend, int n,
+                                     int h, int w, int ci, int co, int kh, int kw, int stride, int dtype,
+                                     void* stream) {
+    if (check_conv("conv2d_transpose_nhwc_dgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(dy && w_packed_fwd && dx, "conv2d_transpose_nhwc_dgrad: null pointer");
+    return conv_fwd_impl(dy, w_packed_fwd, nullptr, dx, nullptr, addend, n, h * stride, w * stride, co, ci, kh, kw, stride, 0, dtype, S(stream));
+}
+
+int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co,
+                                     int kh, int kw, int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_transpose_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && dy && dw, "conv2d_transpose_nhwc_wgrad: null pointer");
+    return conv_wgrad_impl(dy, x, dw, n, h * stride, w * stride, co, ci, kh, kw, stride, dtype, S(stream));
+}
+
+long stmi_instance_norm_ws_floats(int n, int h, int w, int c) { return in_ws_floats(n, h, w, c); }
+
+int stmi_instance_norm_nhwc_stats(const void* x, float* ws, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && ws && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_stats: bad arguments");
+    if (n == 0) return STMI_OK;
+    return in_stats_impl(x, ws, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_apply(const void* x, const float* ws, const float* scale, const float* shift,
+                                  const void* residual, void* y, float* y_f32, float* stats_out, float eps, int act,
+                                  int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && ws && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_apply: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_apply: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_apply_impl(x, ws, scale, shift, residual, y, y_f32, stats_out, eps, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats, const float* scale,
+                                const float* shift, void* dx, float* dscale, float* dshift, float* ws, float eps,
+                                int act, int n, int h, int w, int c, int dtype, void* stream) {
+    (void)eps;  // 1/sqrt(var+eps) is taken from `stats`
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && dy && stats && scale && shift && dx && dscale && dshift && ws && n >= 0 && h > 0 && w > 0 && c > 0,
+                 "instance_norm_nhwc_bwd: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_bwd_impl(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_scale_shift(const float* x, const float* mean, void* y, float scale, long count, int c, int dtype,
+                     void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && mean && y && count >= 0 && c > 0, "scale_shift: bad arguments");
+    if (count == 0) return STMI_OK;
+    return scale_shift_impl(x, mean, y, scale, count, c, dtype, S(stream));
+}
+
+int stmi_maxpool2x2_same_fwd(const void* x, void* y, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && y && n >= 0 && h > 0 && w > 0 && c > 0, "maxpool2x2_same_fwd: bad arguments");
+    if (n == 0) return STMI_OK;
+    return pool_fwd_impl(x, y, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_maxpool2x2_same_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int dtype,
+                             void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && dy && dx && n >= 0 && h > 0 && w > 0 && c > 0, "maxpool2x2_same_bwd: bad arguments");
+    if (n == 0) return STMI_OK;
+    return pool_bwd_impl(x, dy, dx, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(f && g && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_fwd: bad arguments");
+    if (n == 0) return STMI_OK;
+    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_gram_nhwc_bwd(const void* f, const void* s, void* df, int accumulate, int n, int h, int w, int c, int dtype,
+                       void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(f && s && df && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_bwd: bad arguments");
+    if (n == 0) return STMI_OK;
+    return gram_bwd_impl(f, s, df, accumulate, n, h, w, c, dtype, S(stream));
+}
+
+long stmi_gram_packed_elems(int n, int c) {
+    const PackGeom g = pack_geom(1, 1, c, c, STMI_PACK_FWD);
+    return (long)n * g.rows_pad * g.kpad;
+}
+
+int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* loss, float loss_scale,
+                          float grad_scale, int n, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(g && target && s_out && loss && n >= 0 && c > 0 && c % 8 == 0, "gram_mse_fwd_bwd: bad arguments (c=%d)", c);
+    if (n == 0) return STMI_OK;
+    return gram_mse_impl(g, target, s_out, loss, loss_scale, grad_scale, n, c, dtype, S(stream));
+}
+
+int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* loss, float loss_scale, float grad_scale,
+                     long count, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(a && b && loss && count >= 0, "mse_fwd_bwd: bad arguments");
+    if (count == 0) return STMI_OK;
+    return mse_impl(a, b, grad, loss, loss_scale, grad_scale, count, dtype, S(stream));
+}
+
+int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight, int n, int h, int w, int c,
+                         int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(img && grad && loss && n >= 0 && h > 0 && w > 0 && c > 0, "tv_loss_fwd_bwd: bad arguments");
+    if (n == 0) return STMI_OK;
+    return tv_impl(img, grad, loss, weight, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count, float lr, float beta1, float beta2,
+                  float eps, float grad_scale, int* step_dev, int t, void* stream) {
+    STMI_REQUIRE(p && g && m && v && count >= 0, "adam_tf1: bad arguments");
+    STMI_REQUIRE(step_dev || t >= 1, "adam_tf1: step t must be >= 1 (got %d)", t);
+    if (count == 0) return STMI_OK;
+    return adam_impl(p, g, m, v, count, lr, beta1, beta2, eps, grad_scale, step_dev, t, S(stream));
+}
+
+int stmi_cast(const void* src, void* dst, long count, int dtype, int to_f32, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(src && dst && count >= 0, "cast: bad arguments");
+    if (count == 0) return STMI_OK;
+    return cast_impl(src, dst, count, dtype, to_f32, S(stream));
+}
+
+int stmi_clip(float* x, long count, float lo, float hi, void* stream) {
+    STMI_REQUIRE(x && count >= 0, "clip: bad arguments");
+    if (count == 0) return STMI_OK;
+    return clip_impl(x, count, lo, hi, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,480 @@
+// Gather-GEMM convolution for gfx950.
+//
+// One kernel serves every data-path contraction of the stylizer and of VGG19:
+//   conv2d forward, conv2d backward-data (= transposed-conv forward),
+//   transposed-conv backward-data (= conv2d forward) and the Gram backward
+//   (a 1x1 conv with per-sample weights).
+//
+// GEMM view (per block):  D[co][pixel] = sum_taps sum_k  Wp[tap][co][k] * In[pixel @ tap][k]
+//   - rows  = output channels, read from a packed, K-contiguous weight copy
+//   - cols  = output pixels of a (possibly strided) output sub-grid
+//   - a tap = one (dy,dx) input offset with `klen` contiguous K elements.  With
+//     >= 8 input channels klen is the channel count; with fewer (RGB inputs,
+//     3-channel gradients) a tap is a whole kernel ROW: kw*C contiguous NHWC
+//     elements, validity checked per element.
+//   - stride-s backward-data is run once per output parity class so that only
+//     the taps that actually hit an input pixel are multiplied.
+// Accumulators are laid out co-major (row = 4*(lane>>4)+reg), so a lane owns 4
+// consecutive channels of one pixel and the epilogue stores 8 or 16 bytes per
+// lane into NHWC.
+#include "common.hpp"
+
+namespace stmi {
+
+struct ConvGemmParams {
+    const void* in;
+    const void* wp;
+    void* out;
+    void* out_pre;
+    const float* bias;
+    const void* mask;
+    const void* addend;
+    int N, Hi, Wi, Ci;  // gathered tensor
+    int Ho, Wo, Co;     // written tensor
+    int Hs, Ws, oy0, ox0, oys, oxs;  // output sub-grid
+    int in_stride;      // input base position = sub-grid index * in_stride
+    int ntaps, klen, kpad, cdiv, co_pad;
+    long w_batch_stride;  // != 0: one weight set per sample (Gram backward)
+    float alpha;
+    int relu;
+    Tap taps[kMaxTaps];
+};
+
+// chunk swizzle of a 64-byte LDS row: conflict-free ds_read_b128 for the
+// 16-row x 4-chunk fragment pattern (rows r and r+4 land on distinct slots
+// inside every 16-lane service group).
+__device__ __forceinline__ int row_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <typename T, int TC, int TP, int WC, int WP>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+    static_assert(WC * WP == 4, "4 waves per block");
+    constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+    constexpr int BK = 4 * EPC;          // K elements per step (64 bytes per row)
+    constexpr int BLK_CO = 16 * TC * WC;
+    constexpr int BLK_PIX = 16 * TP * WP;
+    constexpr int NW = (BLK_CO * 4 + 255) / 256;
+    constexpr int NP = (BLK_PIX * 4 + 255) / 256;
+    typedef typename Mma<T>::frag frag;
+
+    __shared__ uint4 lds[2][(BLK_CO + BLK_PIX) * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wpx = wave % WP;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int co0 = blockIdx.y * BLK_CO;
+    const long pix0 = (long)blockIdx.x * BLK_PIX;
+    const int z = blockIdx.z;
+    const int HWs = p.Hs * p.Ws;
+    const bool batched = p.w_batch_stride != 0;
+    const long Mz = batched ? (long)HWs : (long)p.N * HWs;
+    const long zoff = batched ? (long)z * HWs : 0;
+    const T* in = (const T*)p.in;
+    const T* wp = (const T*)p.wp + (long)z * p.w_batch_stride;
+
+    // per-thread gather rows
+    int pn[NP], py[NP], px[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        const int row = (tid + 256 * q) >> 2;
+        const long m = pix0 + row;
+        if (row < BLK_PIX && m < Mz) {
+            const long mm = m + zoff;
+            const int n = (int)(mm / HWs);
+            const int rem = (int)(mm - (long)n * HWs);
+            const int i = rem / p.Ws;
+            pn[q] = n;
+            py[q] = i * p.in_stride;
+            px[q] = (rem - i * p.Ws) * p.in_stride;
+        } else {
+            pn[q] = 0;
+            py[q] = -(1 << 20);
+            px[q] = 0;
+        }
+    }
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 wreg[NW], preg[NP];
+
+    auto gload = [&](int t, int k0) {
+        const Tap tap = p.taps[t];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const int idx = tid + 256 * q;
+            const int row = idx >> 2, c = idx & 3;
+            if (row < BLK_CO)
+                wreg[q] = *reinterpret_cast<const uint4*>(
+                    wp + ((long)tap.widx * p.co_pad + co0 + row) * p.kpad + k0 + c * EPC);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const int idx = tid + 256 * q;
+            const int c = idx & 3;
+            const int iy = py[q] + tap.dy, ix = px[q] + tap.dx;
+            const int e0 = k0 + c * EPC;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (p.cdiv == 0) {
+                if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && e0 < p.klen)
+                    v = *reinterpret_cast<const uint4*>(
+                        in + (((long)pn[q] * p.Hi + iy) * p.Wi + ix) * p.Ci + e0);
+            } else if ((unsigned)iy < (unsigned)p.Hi) {
+                const long base = (((long)pn[q] * p.Hi + iy) * p.Wi + ix) * p.Ci;
+                T tmp[EPC];
+#pragma unroll
+                for (int u = 0; u < EPC; u++) {
+                    const int e = e0 + u;
+                    const int xx = ix + e / p.cdiv;
+                    tmp[u] = (e < p.klen && (unsigned)xx < (unsigned)p.Wi) ? in[base + e] : from_f32<T>(0.f);
+                }
+                v = *reinterpret_cast<const uint4*>(tmp);
+            }
+            preg[q] = v;
+        }
+    };
+
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const int idx = tid + 256 * q;
+            const int row = idx >> 2, c = idx & 3;
+            if (row < BLK_CO) lds[buf][row * 4 + (c ^ row_swz(row))] = wreg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const int idx = tid + 256 * q;
+            const int row = idx >> 2, c = idx & 3;
+            if (row < BLK_PIX) lds[buf][(BLK_CO + row) * 4 + (c ^ row_swz(row))] = preg[q];
+        }
+    };
+
+    auto compute = [&](int buf) {
+        frag a[TC], b[TP];
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++) {
+            const int row = (wc * TC + tc) * 16 + r16;
+            const uint4 raw = lds[buf][row * 4 + (g ^ row_swz(row))];
+            a[tc] = *reinterpret_cast<const frag*>(&raw);
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            const int row = (wpx * TP + tp) * 16 + r16;
+            const uint4 raw = lds[buf][(BLK_CO + row) * 4 + (g ^ row_swz(row))];
+            b[tp] = *reinterpret_cast<const frag*>(&raw);
+        }
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) Mma<T>::mma(a[tc], b[tp], acc[tc][tp]);
+    };
+
+    const int ksteps = p.kpad / BK;
+    const int nsteps = p.ntaps * ksteps;
+    if (nsteps > 0) {
+        int t = 0, ks = 0;
+        gload(0, 0);
+        sstore(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; s++) {
+            const bool more = s + 1 < nsteps;
+            if (more) {
+                if (++ks == ksteps) { ks = 0; ++t; }
+                gload(t, ks * BK);
+            }
+            compute(s & 1);
+            if (more) sstore((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane owns channels co..co+3 of pixel column r16 in every tile
+    T* out = (T*)p.out;
+    T* out_pre = (T*)p.out_pre;
+    const T* mask = (const T*)p.mask;
+    const T* addend = (const T*)p.addend;
+    const bool vec_ok = (p.Co & 3) == 0;
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++) {
+        const long m = pix0 + (wpx * TP + tp) * 16 + r16;
+        if (m >= Mz) continue;
+        const long mm = m + zoff;
+        const int n = (int)(mm / HWs);
+        const int rem = (int)(mm - (long)n * HWs);
+        const int i = rem / p.Ws, j = rem - i * p.Ws;
+        const long off = (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++) {
+            const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
+            if (co >= p.Co) continue;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = acc[tc][tp][u];
+            if (p.bias) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (co + u < p.Co) v[u] += p.bias[co + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] *= p.alpha;
+            if (vec_ok) {
+                if (mask) {
+                    float mk[4];
+                    load_vec<T, 4>(mask + off + co, mk);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
+                }
+                if (addend) {
+                    float ad[4];
+                    load_vec<T, 4>(addend + off + co, ad);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] += ad[u];
+                }
+                if (out_pre) store_vec<T, 4>(out_pre + off + co, v);
+                if (p.relu) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = fmaxf(v[u], 0.f);
+                }
+                store_vec<T, 4>(out + off + co, v);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (co + u >= p.Co) continue;
+                    float x = v[u];
+                    if (mask) x = to_f32<T>(mask[off + co + u]) > 0.f ? x : 0.f;
+                    if (addend) x += to_f32<T>(addend[off + co + u]);
+                    if (out_pre) out_pre[off + co + u] = from_f32<T>(x);
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    out[off + co + u] = from_f32<T>(x);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T, int TC, int TP, int WC, int WP>
+static int launch_cfg(const ConvGemmParams& p, long Mz, int nz, hipStream_t s) {
+    constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
+    dim3 grid((unsigned)ceil_div(Mz, BLK_PIX), (unsigned)(p.co_pad / BLK_CO), (unsigned)nz);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, TC, TP, WC, WP>), grid, dim3(256), 0, s, p);
+    STMI_LAUNCH_CHECK("conv_gemm_kernel");
+    return STMI_OK;
+}
+
+template <typename T>
+static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
+    const bool batched = p.w_batch_stride != 0;
+    const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
+    const int nz = batched ? p.N : 1;
+    if (Mz <= 0) return STMI_OK;
+    const int rows = p.co_pad;
+    if (rows % 128 == 0) {
+        const long blocks = (long)ceil_div(Mz, 128) * (rows / 128) * nz;
+        if (blocks >= 384) return launch_cfg<T, 4, 4, 2, 2>(p, Mz, nz, s);
+        return launch_cfg<T, 2, 2, 2, 2>(p, Mz, nz, s);
+    }
+    if (rows % 64 == 0) {
+        const long blocks = (long)ceil_div(Mz, 256) * (rows / 64) * nz;
+        if (blocks >= 384) return launch_cfg<T, 4, 4, 1, 4>(p, Mz, nz, s);
+        return launch_cfg<T, 2, 2, 2, 2>(p, Mz, nz, s);
+    }
+    if (rows % 32 == 0) return launch_cfg<T, 2, 4, 1, 4>(p, Mz, nz, s);
+    return launch_cfg<T, 1, 4, 1, 4>(p, Mz, nz, s);
+}
+
+int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t s) {
+    if (dtype == STMI_BF16) return launch_typed<bf16_t>(p, s);
+    return launch_typed<float>(p, s);
+}
+
+// rows of a packed weight set are padded so that every block tile height divides them
+int packed_rows(int rows) {
+    if (rows > 64) return round_up(rows, 128);
+    if (rows > 32) return 64;
+    if (rows > 16) return 32;
+    return 16;
+}
+
+static bool row_mode(int kchannels) { return (kchannels % 8) != 0; }
+
+// mode FWD : rows = co, K = ci     mode DGRAD: rows = ci, K = co
+PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
+    PackGeom g;
+    const int kch = mode == STMI_PACK_FWD ? ci : co;
+    g.rows = mode == STMI_PACK_FWD ? co : ci;
+    g.rows_pad = packed_rows(g.rows);
+    g.row = row_mode(kch);
+    g.ntaps = g.row ? kh : kh * kw;
+    g.klen = g.row ? kw * kch : kch;
+    g.kpad = round_up(g.klen, 32);
+    return g;
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int kh, int kw, int ci, int co,
+                                    int mode, PackGeom g) {
+    const long total = (long)g.ntaps * g.rows_pad * g.kpad;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % g.kpad);
+        const int row = (int)((idx / g.kpad) % g.rows_pad);
+        const int t = (int)(idx / ((long)g.kpad * g.rows_pad));
+        float v = 0.f;
+        if (row < g.rows && e < g.klen) {
+            int ky, kx, kc;
+            const int kch = mode == STMI_PACK_FWD ? ci : co;
+            if (g.row) {
+                ky = t;
+                const int pos = e / kch;
+                kc = e - pos * kch;
+                // forward rows run left to right over kx; backward-data rows
+                // visit the taps in ascending pixel order, i.e. descending kx
+                kx = mode == STMI_PACK_FWD ? pos : kw - 1 - pos;
+            } else {
+                ky = t / kw;
+                kx = t - ky * kw;
+                kc = e;
+            }
+            const int c_in = mode == STMI_PACK_FWD ? kc : row;
+            const int c_out = mode == STMI_PACK_FWD ? row : kc;
+            v = w[(((long)ky * kw + kx) * ci + c_in) * co + c_out];
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
+// Builds the tap table of a forward convolution (gathers x, writes y).
+static int setup_fwd(ConvGemmParams& p, int n, int h, int w, int ci, int co, int kh, int kw, int stride) {
+    int ho, wo, pt, pl;
+    same_pads(h, kh, stride, &ho, &pt);
+    same_pads(w, kw, stride, &wo, &pl);
+    const PackGeom g = pack_geom(kh, kw, ci, co, STMI_PACK_FWD);
+    STMI_REQUIRE(g.ntaps <= kMaxTaps, "conv fwd: %d taps exceed the table (%d)", g.ntaps, kMaxTaps);
+    STMI_REQUIRE(!g.row || stride == 1, "conv fwd: fewer than 8 input channels needs stride 1 (ci=%d stride=%d)", ci, stride);
+    p.N = n; p.Hi = h; p.Wi = w; p.Ci = ci;
+    p.Ho = ho; p.Wo = wo; p.Co = co;
+    p.Hs = ho; p.Ws = wo; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
+    p.in_stride = stride;
+    p.ntaps = g.ntaps; p.klen = g.klen; p.kpad = g.kpad; p.co_pad = g.rows_pad;
+    p.cdiv = g.row ? ci : 0;
+    for (int t = 0; t < g.ntaps; t++) {
+        if (g.row) {
+            p.taps[t].dy = (short)(t - pt); p.taps[t].dx = (short)(-pl); p.taps[t].widx = t;
+        } else {
+            const int ky = t / kw, kx = t % kw;
+            p.taps[t].dy = (short)(ky - pt); p.taps[t].dx = (short)(kx - pl); p.taps[t].widx = t;
+        }
+    }
+    return STMI_OK;
+}
+
+static void clear_params(ConvGemmParams& p) {
+    memset(&p, 0, sizeof(p));
+    p.alpha = 1.f;
+}
+
+int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
+                  int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype,
+                  hipStream_t s) {
+    ConvGemmParams p;
+    clear_params(p);
+    int rc = setup_fwd(p, n, h, w, ci, co, kh, kw, stride);
+    if (rc) return rc;
+    p.in = x; p.wp = wp; p.out = y; p.out_pre = y_pre; p.bias = bias; p.addend = addend; p.relu = relu;
+    return launch_conv_gemm(p, dtype, s);
+}
+
+// Backward-data of conv(n,h,w,ci -> co, k, stride): gathers dy, writes dx.
+int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
+                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s) {
+    int ho, wo, pt, pl;
+    same_pads(h, kh, stride, &ho, &pt);
+    same_pads(w, kw, stride, &wo, &pl);
+    const PackGeom g = pack_geom(kh, kw, ci, co, STMI_PACK_DGRAD);
+    STMI_REQUIRE(!g.row || stride == 1, "conv dgrad: fewer than 8 output channels needs stride 1 (co=%d stride=%d)", co, stride);
+    ConvGemmParams p;
+    clear_params(p);
+    p.in = dy; p.wp = wp; p.out = dx; p.mask = mask; p.addend = addend; p.alpha = alpha;
+    p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = co;
+    p.Ho = h; p.Wo = w; p.Co = ci;
+    p.klen = g.klen; p.kpad = g.kpad; p.co_pad = g.rows_pad;
+    p.cdiv = g.row ? co : 0;
+    p.in_stride = 1;
+    if (stride == 1) {
+        STMI_REQUIRE(g.ntaps <= kMaxTaps, "conv dgrad: %d taps exceed the table", g.ntaps);
+        p.Hs = h; p.Ws = w; p.oy0 = 0; p.ox0 = 0; p.oys = 1; p.oxs = 1;
+        p.ntaps = g.ntaps;
+        for (int t = 0; t < g.ntaps; t++) {
+            if (g.row) {
+                p.taps[t].dy = (short)(pt - t); p.taps[t].dx = (short)(pl - (kw - 1)); p.taps[t].widx = t;
+            } else {
+                const int ky = t / kw, kx = t % kw;
+                p.taps[t].dy = (short)(pt - ky); p.taps[t].dx = (short)(pl - kx); p.taps[t].widx = t;
+            }
+        }
+        return launch_conv_gemm(p, dtype, s);
+    }
+    // one launch per output parity class: input row = (iy + pt - ky) / stride must be integral
+    for (int cy = 0; cy < stride; cy++) {
+        for (int cx = 0; cx < stride; cx++) {
+            p.oy0 = cy; p.ox0 = cx; p.oys = stride; p.oxs = stride;
+            p.Hs = (h - cy + stride - 1) / stride;
+            p.Ws = (w - cx + stride - 1) / stride;
+            if (p.Hs <= 0 || p.Ws <= 0) continue;
+            int nt = 0;
+            for (int ky = 0; ky < kh; ky++) {
+                const int ny = cy + pt - ky;
+                if (((ny % stride) + stride) % stride) continue;
+                for (int kx = 0; kx < kw; kx++) {
+                    const int nx = cx + pl - kx;
+                    if (((nx % stride) + stride) % stride) continue;
+                    STMI_REQUIRE(nt < kMaxTaps, "conv dgrad: tap table overflow");
+                    // exact division, also for negative numerators
+                    p.taps[nt].dy = (short)((ny - (((ny % stride) + stride) % stride)) / stride);
+                    p.taps[nt].dx = (short)((nx - (((nx % stride) + stride) % stride)) / stride);
+                    p.taps[nt].widx = ky * kw + kx;
+                    nt++;
+                }
+            }
+            p.ntaps = nt;
+            int rc = launch_conv_gemm(p, dtype, s);
+            if (rc) return rc;
+        }
+    }
+    return STMI_OK;
+}
+
+int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
+                  hipStream_t s) {
+    ConvGemmParams p;
+    clear_params(p);
+    p.in = f; p.wp = sp; p.out = df; p.addend = accumulate ? df : nullptr;
+    p.N = n; p.Hi = h; p.Wi = w; p.Ci = c;
+    p.Ho = h; p.Wo = w; p.Co = c;
+    p.Hs = h; p.Ws = w; p.oys = 1; p.oxs = 1;
+    p.in_stride = 1;
+    p.ntaps = 1; p.klen = c; p.kpad = round_up(c, 32); p.co_pad = packed_rows(c);
+    p.cdiv = 0;
+    p.taps[0].dy = 0; p.taps[0].dx = 0; p.taps[0].widx = 0;
+    p.w_batch_stride = (long)p.co_pad * p.kpad;
+    STMI_REQUIRE(c % 8 == 0, "gram bwd: channel count must be a multiple of 8 (c=%d)", c);
+    return launch_conv_gemm(p, dtype, s);
+}
+
+int pack_weights_impl(const float* w, void* out, int kh, int kw, int ci, int co, int mode, int dtype, hipStream_t s) {
+    const PackGeom g = pack_geom(kh, kw, ci, co, mode);
+    const long total = (long)g.ntaps * g.rows_pad * g.kpad;
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)out, kh, kw, ci, co, mode, g);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, w, (float*)out, kh, kw, ci, co, mode, g);
+    STMI_LAUNCH_CHECK("pack_weights_kernel");
+    return STMI_OK;
+}
+
+}  // namespace stmi

@@ -1,0 +1,303 @@
+// Bandwidth-bound kernels of the style-transfer path on gfx950: VGG input
+// scaling, 2x2 SAME max-pool (forward and routed backward), fused loss
+// reductions (content / Gram MSE, total variation) that emit the scaled
+// gradient in the same pass, TF1-style Adam, dtype casts.
+#include "common.hpp"
+
+namespace stmi {
+
+static inline int flat_blocks(long work_items) {
+    long b = (work_items + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- scale/shift
+template <typename T>
+__global__ void scale_shift_kernel(const float* __restrict__ x, const float* __restrict__ mean, T* __restrict__ y,
+                                   float scale, long count, int c) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(x[i] * scale - mean[i % c]);
+}
+
+int scale_shift_impl(const float* x, const float* mean, void* y, float scale, long count, int c, int dtype,
+                     hipStream_t s) {
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(scale_shift_kernel<bf16_t>, dim3(flat_blocks(count)), dim3(256), 0, s, x, mean, (bf16_t*)y, scale, count, c);
+    else
+        hipLaunchKernelGGL(scale_shift_kernel<float>, dim3(flat_blocks(count)), dim3(256), 0, s, x, mean, (float*)y, scale, count, c);
+    STMI_LAUNCH_CHECK("scale_shift_kernel");
+    return STMI_OK;
+}
+
+// ---------------------------------------------------------------------- casts
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long count) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        dst[i] = from_f32<D>(to_f32<S>(src[i]));
+}
+
+int cast_impl(const void* src, void* dst, long count, int dtype, int to_f32_flag, hipStream_t s) {
+    const dim3 grid(flat_blocks(count)), block(256);
+    if (dtype == STMI_BF16) {
+        if (to_f32_flag) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)src, (float*)dst, count);
+        else hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, s, (const float*)src, (bf16_t*)dst, count);
+    } else {
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, (const float*)src, (float*)dst, count);
+    }
+    STMI_LAUNCH_CHECK("cast_kernel");
+    return STMI_OK;
+}
+
+__global__ void clip_kernel(float* x, long count, float lo, float hi) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+int clip_impl(float* x, long count, float lo, float hi, hipStream_t s) {
+    hipLaunchKernelGGL(clip_kernel, dim3(flat_blocks(count)), dim3(256), 0, s, x, count, lo, hi);
+    STMI_LAUNCH_CHECK("clip_kernel");
+    return STMI_OK;
+}
+
+// ------------------------------------------------------------------- max pool
+// one thread = one output window x V channels
+template <typename T, int V>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2, cg = c / V;
+    const long total = (long)n * ho * wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long r = i / cg;
+        const int ox = (int)(r % wo); r /= wo;
+        const int oy = (int)(r % ho);
+        const int b = (int)(r / ho);
+        float m[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) m[j] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+                if (iy < h && ix < w) {
+                    float v[V];
+                    load_vec<T, V>(x + (((long)b * h + iy) * w + ix) * c + g * V, v);
+#pragma unroll
+                    for (int j = 0; j < V; j++) m[j] = fmaxf(m[j], v[j]);
+                }
+            }
+        store_vec<T, V>(y + (((long)b * ho + oy) * wo + ox) * c + g * V, m);
+    }
+}
+
+template <typename T, int V>
+__global__ void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int n, int h,
+                                int w, int c) {
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2, cg = c / V;
+    const long total = (long)n * ho * wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long r = i / cg;
+        const int ox = (int)(r % wo); r /= wo;
+        const int oy = (int)(r % ho);
+        const int b = (int)(r / ho);
+        float v[4][V], m[V], d[V];
+        bool taken[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) { m[j] = -INFINITY; taken[j] = false; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            if (iy < h && ix < w) {
+                load_vec<T, V>(x + (((long)b * h + iy) * w + ix) * c + g * V, v[k]);
+#pragma unroll
+                for (int j = 0; j < V; j++) m[j] = fmaxf(m[j], v[k][j]);
+            }
+        }
+        load_vec<T, V>(dy + (((long)b * ho + oy) * wo + ox) * c + g * V, d);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            if (iy < h && ix < w) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    // first maximum of the window takes the gradient; the ReLU
+                    // that produced x passes it only where x > 0
+                    const bool hit = !taken[j] && v[k][j] == m[j];
+                    taken[j] = taken[j] || hit;
+                    o[j] = (hit && v[k][j] > 0.f) ? d[j] : 0.f;
+                }
+                store_vec<T, V>(dx + (((long)b * h + iy) * w + ix) * c + g * V, o);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int pool_typed(bool bwd, const void* x, const void* dy, void* out, int n, int h, int w, int c, hipStream_t s) {
+    constexpr int VMAX = 16 / (int)sizeof(T);
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    if (c % VMAX == 0) {
+        const dim3 grid(flat_blocks((long)n * ho * wo * (c / VMAX)));
+        if (bwd) hipLaunchKernelGGL((pool_bwd_kernel<T, VMAX>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, n, h, w, c);
+        else hipLaunchKernelGGL((pool_fwd_kernel<T, VMAX>), grid, dim3(256), 0, s, (const T*)x, (T*)out, n, h, w, c);
+    } else {
+        const dim3 grid(flat_blocks((long)n * ho * wo * c));
+        if (bwd) hipLaunchKernelGGL((pool_bwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, n, h, w, c);
+        else hipLaunchKernelGGL((pool_fwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (T*)out, n, h, w, c);
+    }
+    STMI_LAUNCH_CHECK("pool kernel");
+    return STMI_OK;
+}
+
+int pool_fwd_impl(const void* x, void* y, int n, int h, int w, int c, int dtype, hipStream_t s) {
+    return dtype == STMI_BF16 ? pool_typed<bf16_t>(false, x, nullptr, y, n, h, w, c, s)
+                              : pool_typed<float>(false, x, nullptr, y, n, h, w, c, s);
+}
+
+int pool_bwd_impl(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int dtype, hipStream_t s) {
+    return dtype == STMI_BF16 ? pool_typed<bf16_t>(true, x, dy, dx, n, h, w, c, s)
+                              : pool_typed<float>(true, x, dy, dx, n, h, w, c, s);
+}
+
+// --------------------------------------------------------------------- losses
+// loss[0] += loss_scale * sum((a-b)^2); grad = grad_scale * (a-b)
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ grad,
+                                                  float* loss, float loss_scale, float grad_scale, long count) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float d = to_f32<T>(a[i]) - to_f32<T>(b[i]);
+        acc += d * d;
+        if (grad) grad[i] = from_f32<T>(grad_scale * d);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
+}
+
+int mse_impl(const void* a, const void* b, void* grad, float* loss, float loss_scale, float grad_scale, long count,
+             int dtype, hipStream_t s) {
+    const dim3 grid(flat_blocks((count + 3) / 4));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(mse_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)grad, loss, loss_scale, grad_scale, count);
+    else
+        hipLaunchKernelGGL(mse_kernel<float>, grid, dim3(256), 0, s, (const float*)a, (const float*)b, (float*)grad, loss, loss_scale, grad_scale, count);
+    STMI_LAUNCH_CHECK("mse_kernel");
+    return STMI_OK;
+}
+
+// Gram form: g fp32 [n,c,c] against target fp32 [c,c]; writes the scaled
+// difference into the K-contiguous padded layout the Gram-backward GEMM reads
+// ([n][rows_pad][kpad], zero padding).
+template <typename T>
+__global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__ g, const float* __restrict__ target,
+                                                       T* __restrict__ sout, float* loss, float loss_scale,
+                                                       float grad_scale, int n, int c, int rows_pad, int kpad) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long total = (long)n * rows_pad * kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % kpad);
+        const int row = (int)((i / kpad) % rows_pad);
+        const int b = (int)(i / ((long)kpad * rows_pad));
+        float v = 0.f;
+        if (row < c && col < c) {
+            const float d = g[((long)b * c + row) * c + col] - target[(long)row * c + col];
+            acc += d * d;
+            v = grad_scale * d;
+        }
+        sout[i] = from_f32<T>(v);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
+}
+
+int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, float loss_scale, float grad_scale,
+                  int n, int c, int dtype, hipStream_t s) {
+    const int rows_pad = packed_rows(c), kpad = round_up(c, 32);
+    const dim3 grid(flat_blocks((long)n * rows_pad * kpad));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(gram_mse_kernel<bf16_t>, grid, dim3(256), 0, s, g, target, (bf16_t*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+    else
+        hipLaunchKernelGGL(gram_mse_kernel<float>, grid, dim3(256), 0, s, g, target, (float*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+    STMI_LAUNCH_CHECK("gram_mse_kernel");
+    return STMI_OK;
+}
+
+// total variation: one thread per element; forward differences to the right
+// and below feed the loss, the gradient gathers the up-to-four differences the
+// element takes part in.
+template <typename T>
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, T* __restrict__ grad, float* loss,
+                                                 float wx, float wy, int n, int h, int w, int c) {
+    __shared__ float red[4];
+    const long total = (long)n * h * w * c;
+    const long rowst = (long)w * c;
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / c;
+        const int x = (int)(pix % w);
+        const int y = (int)((pix / w) % h);
+        const float v = img[i];
+        float gsum = 0.f;
+        if (x + 1 < w) { const float d = img[i + c] - v; acc += wx * d * d; gsum -= 2.f * wx * d; }
+        if (x > 0) { const float d = v - img[i - c]; gsum += 2.f * wx * d; }
+        if (y + 1 < h) { const float d = img[i + rowst] - v; acc += wy * d * d; gsum -= 2.f * wy * d; }
+        if (y > 0) { const float d = v - img[i - rowst]; gsum += 2.f * wy * d; }
+        grad[i] = from_f32<T>(gsum);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss, tot);
+}
+
+int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int h, int w, int c, int dtype,
+            hipStream_t s) {
+    // reduce_mean over [n,h,w-1,c] and [n,h-1,w,c]; a 1-wide axis gives an empty mean (NaN in TF): treated as 0 here
+    const float wx = w > 1 ? weight / ((float)n * h * (w - 1) * c) : 0.f;
+    const float wy = h > 1 ? weight / ((float)n * (h - 1) * w * c) : 0.f;
+    const dim3 grid(flat_blocks((long)n * h * w * c));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, n, h, w, c);
+    else
+        hipLaunchKernelGGL(tv_kernel<float>, grid, dim3(256), 0, s, img, (float*)grad, loss, wx, wy, n, h, w, c);
+    STMI_LAUNCH_CHECK("tv_kernel");
+    return STMI_OK;
+}
+
+// ----------------------------------------------------------------------- Adam
+__global__ void bump_step_kernel(int* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long count, float lr, float b1, float b2, float eps,
+                            float grad_scale, const int* step_dev, int t_host) {
+    const int t = step_dev ? step_dev[0] : t_host;
+    // double keeps 1-b2^t exact enough for small t (b2 = .999)
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int adam_impl(float* p, const float* g, float* m, float* v, long count, float lr, float b1, float b2, float eps,
+              float grad_scale, int* step_dev, int t, hipStream_t s) {
+    if (step_dev) {
+        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_dev);
+        STMI_LAUNCH_CHECK("bump_step_kernel");
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(count)), dim3(256), 0, s, p, g, m, v, count, lr, b1, b2, eps, grad_scale, (const int*)step_dev, t);
+    STMI_LAUNCH_CHECK("adam_kernel");
+    return STMI_OK;
+}
+
+}  // namespace stmi

@@ -1,0 +1,320 @@
+"""Torch-tensor front end of the C-ABI: shape/dtype checks, output allocation,
+current-stream plumbing.  Every function launches HIP kernels from
+libstmi355.so; nothing here computes on the host and nothing falls back to
+torch operators.
+
+Tensors are NHWC, contiguous, on the current HIP device, float32 or bfloat16.
+"""
+import torch
+
+from . import lib as _lib
+from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD  # noqa: F401
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError('stmi ops take float32 or bfloat16 tensors, got %s' % t.dtype)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=None, shape=None):
+    if not t.is_cuda:
+        raise _lib.StmiError('%s must live on the GPU: the HIP kernels have no CPU fallback' % name)
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError('%s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+def same_out(size, stride):
+    return -(-size // stride)
+
+
+# ---------------------------------------------------------------- weights
+def packed_elems(kh, kw, ci, co, mode):
+    return _lib.load().stmi_conv_packed_elems(kh, kw, ci, co, mode)
+
+
+def pack_conv_weights(w_hwio, mode, dtype, out=None):
+    """fp32 HWIO [kh,kw,ci,co] -> K-contiguous zero-padded copy in `dtype`."""
+    _chk(w_hwio, 'w_hwio', torch.float32)
+    kh, kw, ci, co = w_hwio.shape
+    n = packed_elems(kh, kw, ci, co, mode)
+    if out is None:
+        out = torch.empty(n, dtype=dtype, device=w_hwio.device)
+    _chk(out, 'packed', dtype, (n,))
+    _lib.call('stmi_pack_conv_weights', w_hwio.data_ptr(), out.data_ptr(), kh, kw, ci, co, mode, _dt(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------- conv
+def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=False, out=None, out_pre=None):
+    """kshape = (kh, kw, ci, co) of the HWIO weight that was packed with PACK_FWD."""
+    kh, kw, ci, co = kshape
+    n, h, w, c = x.shape
+    assert c == ci, (c, ci)
+    _chk(x, 'x')
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, ci, co, PACK_FWD),))
+    oshape = (n, same_out(h, stride), same_out(w, stride), co)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    pre = None
+    if want_pre:
+        pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', x.dtype, oshape)
+    if bias is not None:
+        _chk(bias, 'bias', torch.float32, (co,))
+    _lib.call('stmi_conv2d_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
+              n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x), _stream())
+    return (y, pre) if want_pre else y
+
+
+def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None):
+    """Gradient w.r.t. the conv input of spatial size in_hw; W packed with PACK_DGRAD."""
+    kh, kw, ci, co = kshape
+    h, w = in_hw
+    n = dy.shape[0]
+    _chk(dy, 'dy', shape=(n, same_out(h, stride), same_out(w, stride), co))
+    _chk(w_packed, 'w_packed', dy.dtype, (packed_elems(kh, kw, ci, co, PACK_DGRAD),))
+    oshape = (n, h, w, ci)
+    dx = torch.empty(oshape, dtype=dy.dtype, device=dy.device) if out is None else _chk(out, 'out', dy.dtype, oshape)
+    for t, nm in ((relu_mask, 'relu_mask'), (addend, 'addend')):
+        if t is not None:
+            _chk(t, nm, dy.dtype, oshape)
+    _lib.call('stmi_conv2d_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
+              _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, kshape, stride, out=None):
+    kh, kw, ci, co = kshape
+    n, h, w, c = x.shape
+    assert c == ci
+    _chk(x, 'x')
+    _chk(dy, 'dy', x.dtype, (n, same_out(h, stride), same_out(w, stride), co))
+    dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
+    _lib.call('stmi_conv2d_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co, kh, kw, stride,
+              _dt(x), _stream())
+    return dw
+
+
+def conv2d_transpose_fwd(x, w_packed, kshape, stride, out=None):
+    """kshape = (kh, kw, co, ci) of the reference's transposed-conv weight; packed with
+    PACK_DGRAD as if it were the HWIO weight of a conv co -> ci."""
+    kh, kw, co, ci = kshape
+    n, h, w, c = x.shape
+    assert c == ci
+    _chk(x, 'x')
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, co, ci, PACK_DGRAD),))
+    oshape = (n, h * stride, w * stride, co)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    _lib.call('stmi_conv2d_transpose_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), n, h, w, ci, co,
+              kh, kw, stride, _dt(x), _stream())
+    return y
+
+
+def conv2d_transpose_dgrad(dy, w_packed, kshape, stride, addend=None, out=None):
+    kh, kw, co, ci = kshape
+    n, hs, ws, c = dy.shape
+    assert c == co and hs % stride == 0 and ws % stride == 0
+    h, w = hs // stride, ws // stride
+    _chk(dy, 'dy')
+    _chk(w_packed, 'w_packed', dy.dtype, (packed_elems(kh, kw, co, ci, PACK_FWD),))
+    oshape = (n, h, w, ci)
+    dx = torch.empty(oshape, dtype=dy.dtype, device=dy.device) if out is None else _chk(out, 'out', dy.dtype, oshape)
+    if addend is not None:
+        _chk(addend, 'addend', dy.dtype, oshape)
+    _lib.call('stmi_conv2d_transpose_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(addend),
+              n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
+    return dx
+
+
+def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None):
+    kh, kw, co, ci = kshape
+    n, h, w, c = x.shape
+    assert c == ci
+    _chk(x, 'x')
+    _chk(dy, 'dy', x.dtype, (n, h * stride, w * stride, co))
+    dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
+    _lib.call('stmi_conv2d_transpose_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co,
+              kh, kw, stride, _dt(x), _stream())
+    return dw
+
+
+# ---------------------------------------------------------- instance norm
+IN_EPS = 1e-3
+
+
+def instance_norm_ws(n, h, w, c, device):
+    return torch.empty(_lib.load().stmi_instance_norm_ws_floats(n, h, w, c), dtype=torch.float32, device=device)
+
+
+def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=False, ws=None, out=None, stats=None,
+                      out_f32=None, eps=IN_EPS):
+    """Returns (y, stats[, y_f32]); stats [n,c,2] = (mean, 1/sqrt(var+eps)) for the backward."""
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    _chk(scale, 'scale', torch.float32, (c,))
+    _chk(shift, 'shift', torch.float32, (c,))
+    if ws is None:
+        ws = instance_norm_ws(n, h, w, c, x.device)
+    y = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
+    if stats is None:
+        stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    y32 = None
+    if want_f32:
+        y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out_f32 is None else out_f32
+    if residual is not None:
+        _chk(residual, 'residual', x.dtype, x.shape)
+    s = _stream()
+    _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), n, h, w, c, _dt(x), s)
+    _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), ws.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              _ptr(residual), y.data_ptr(), _ptr(y32), stats.data_ptr(), float(eps), act, n, h, w, c, _dt(x), s)
+    return (y, stats, y32) if want_f32 else (y, stats)
+
+
+def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS):
+    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c])."""
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    _chk(dy, 'dy', x.dtype, x.shape)
+    _chk(stats, 'stats', torch.float32, (n, c, 2))
+    for t, nm in ((scale, 'scale'), (shift, 'shift'), (dscale, 'dscale'), (dshift, 'dshift')):
+        _chk(t, nm, torch.float32, (c,))
+    if ws is None:
+        ws = instance_norm_ws(n, h, w, c, x.device)
+    dx = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
+    _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
+              shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), ws.data_ptr(), float(eps), act,
+              n, h, w, c, _dt(x), _stream())
+    return dx
+
+
+# -------------------------------------------------------------- VGG pieces
+def scale_shift(x_f32, mean, scale, dtype, out=None):
+    _chk(x_f32, 'x', torch.float32)
+    c = x_f32.shape[-1]
+    _chk(mean, 'mean', torch.float32, (c,))
+    y = torch.empty(x_f32.shape, dtype=dtype, device=x_f32.device) if out is None else _chk(out, 'out', dtype, x_f32.shape)
+    _lib.call('stmi_scale_shift', x_f32.data_ptr(), mean.data_ptr(), y.data_ptr(), float(scale), x_f32.numel(), c,
+              _dt(y), _stream())
+    return y
+
+
+def maxpool_fwd(x, out=None):
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    oshape = (n, (h + 1) // 2, (w + 1) // 2, c)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    _lib.call('stmi_maxpool2x2_same_fwd', x.data_ptr(), y.data_ptr(), n, h, w, c, _dt(x), _stream())
+    return y
+
+
+def maxpool_bwd(x, dy, out=None):
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    _chk(dy, 'dy', x.dtype, (n, (h + 1) // 2, (w + 1) // 2, c))
+    dx = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
+    _lib.call('stmi_maxpool2x2_same_bwd', x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h, w, c, _dt(x), _stream())
+    return dx
+
+
+# ------------------------------------------------------------------- Gram
+def gram_fwd(f, out=None):
+    n, h, w, c = f.shape
+    _chk(f, 'f')
+    g = torch.empty((n, c, c), dtype=torch.float32, device=f.device) if out is None else _chk(out, 'out', torch.float32, (n, c, c))
+    _lib.call('stmi_gram_nhwc_fwd', f.data_ptr(), g.data_ptr(), n, h, w, c, _dt(f), _stream())
+    return g
+
+
+def gram_packed_elems(n, c):
+    return _lib.load().stmi_gram_packed_elems(n, c)
+
+
+def gram_bwd(f, s_packed, df, accumulate):
+    n, h, w, c = f.shape
+    _chk(f, 'f')
+    _chk(s_packed, 's_packed', f.dtype, (gram_packed_elems(n, c),))
+    _chk(df, 'df', f.dtype, f.shape)
+    _lib.call('stmi_gram_nhwc_bwd', f.data_ptr(), s_packed.data_ptr(), df.data_ptr(), int(accumulate), n, h, w, c,
+              _dt(f), _stream())
+    return df
+
+
+# ----------------------------------------------------------------- losses
+def gram_mse_fwd_bwd(g, target, loss, loss_scale, grad_scale, dtype, out=None):
+    n, c, _ = g.shape
+    _chk(g, 'g', torch.float32, (n, c, c))
+    _chk(target, 'target', torch.float32)
+    assert target.numel() == c * c, 'style target must be one [c,c] Gram (broadcast over the batch)'
+    _chk(loss, 'loss', torch.float32)
+    ne = gram_packed_elems(n, c)
+    s = torch.empty(ne, dtype=dtype, device=g.device) if out is None else _chk(out, 'out', dtype, (ne,))
+    _lib.call('stmi_gram_mse_fwd_bwd', g.data_ptr(), target.data_ptr(), s.data_ptr(), loss.data_ptr(),
+              float(loss_scale), float(grad_scale), n, c, _dt(s), _stream())
+    return s
+
+
+def mse_fwd_bwd(a, b, loss, loss_scale, grad_scale, want_grad=True, out=None):
+    _chk(a, 'a')
+    _chk(b, 'b', a.dtype, a.shape)
+    _chk(loss, 'loss', torch.float32)
+    grad = None
+    if want_grad:
+        grad = torch.empty_like(a) if out is None else _chk(out, 'out', a.dtype, a.shape)
+    _lib.call('stmi_mse_fwd_bwd', a.data_ptr(), b.data_ptr(), _ptr(grad), loss.data_ptr(), float(loss_scale),
+              float(grad_scale), a.numel(), _dt(a), _stream())
+    return grad
+
+
+def tv_loss_fwd_bwd(img_f32, loss, weight, dtype, out=None):
+    n, h, w, c = img_f32.shape
+    _chk(img_f32, 'img', torch.float32)
+    _chk(loss, 'loss', torch.float32)
+    grad = torch.empty(img_f32.shape, dtype=dtype, device=img_f32.device) if out is None else _chk(out, 'out', dtype, img_f32.shape)
+    _lib.call('stmi_tv_loss_fwd_bwd', img_f32.data_ptr(), grad.data_ptr(), loss.data_ptr(), float(weight), n, h, w, c,
+              _dt(grad), _stream())
+    return grad
+
+
+# -------------------------------------------------------------- optimizer
+def adam_tf1(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, step_dev=None, t=0):
+    for tns, nm in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _chk(tns, nm, torch.float32)
+        assert tns.numel() == p.numel()
+    if step_dev is not None:
+        _chk(step_dev, 'step_dev', torch.int32)
+    _lib.call('stmi_adam_tf1', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
+              float(beta1), float(beta2), float(eps), float(grad_scale), _ptr(step_dev), int(t), _stream())
+
+
+# ------------------------------------------------------------------- misc
+def cast(src, dtype, out=None):
+    _chk(src, 'src')
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device) if out is None else _chk(out, 'out', dtype, src.shape)
+    if src.dtype == torch.float32:
+        _lib.call('stmi_cast', src.data_ptr(), dst.data_ptr(), src.numel(), _dt(dst), 0, _stream())
+    elif dtype == torch.float32:
+        _lib.call('stmi_cast', src.data_ptr(), dst.data_ptr(), src.numel(), _dt(src), 1, _stream())
+    else:
+        raise TypeError('cast converts between float32 and one other dtype')
+    return dst
+
+
+def clip_(x, lo, hi):
+    _chk(x, 'x', torch.float32)
+    _lib.call('stmi_clip', x.data_ptr(), x.numel(), float(lo), float(hi), _stream())
+    return x

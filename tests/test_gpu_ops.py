@@ -1,0 +1,259 @@
+"""Per-kernel parity of the HIP path (through the C-ABI) against the CPU oracle.
+
+fp32 mode: max |err| / max |ref| <= 1e-3 (BASELINE.json north_star tolerance).
+bf16 mode: <= 3e-2 per op (the end-to-end gates are PSNR >= 40 dB / Gram 1e-2).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale)
+
+
+def q(t, dtype):
+    """value as the kernel sees it (rounded to the compute dtype), in float64"""
+    return t.to(dtype).double()
+
+
+CONV_CASES = [
+    # n, h, w, ci, co, k, s
+    (2, 12, 10, 3, 32, 9, 1),     # stylizer conv1 (row taps, RGB input)
+    (2, 12, 10, 32, 64, 3, 2),    # conv2, even size: pads (0,1)
+    (1, 11, 9, 64, 128, 3, 2),    # conv3 on odd size: pads (1,1)
+    (2, 9, 7, 128, 128, 3, 1),    # residual conv
+    (1, 10, 12, 32, 3, 9, 1),     # final conv: 3 output channels
+    (1, 7, 9, 3, 64, 3, 1),       # VGG conv1_1
+    (1, 6, 5, 256, 512, 3, 1),    # VGG conv4_1
+    (3, 5, 5, 8, 16, 3, 1),       # reduced-width VGG layer
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(cuda, dtype, case):
+    from stmi import ops
+    n, h, w, ci, co, k, s = case
+    x = rnd((n, h, w, ci), 1)
+    wt = rnd((k, k, ci, co), 2, 1.0 / np.sqrt(k * k * ci))
+    bias = rnd((co,), 3)
+    xq, wq = q(x, dtype).requires_grad_(), q(wt, dtype).requires_grad_()
+    y_ref = O.conv2d_same(xq, wq, s, bias=bias)
+    dy = rnd(tuple(y_ref.shape), 4)
+    dyq = q(dy, dtype)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, (xq, wq), dyq)
+
+    xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
+    w32 = wt.to(cuda, torch.float32)
+    wf = ops.pack_conv_weights(w32, ops.PACK_FWD, dtype)
+    wd = ops.pack_conv_weights(w32, ops.PACK_DGRAD, dtype)
+    y, pre = ops.conv2d_fwd(xd, wf, (k, k, ci, co), s, bias=bias.to(cuda, torch.float32), relu=True, want_pre=True)
+    assert rel_err(pre, y_ref) <= TOL[dtype]
+    assert rel_err(y, torch.relu(y_ref)) <= TOL[dtype]
+    dx = ops.conv2d_dgrad(dyd, wd, (k, k, ci, co), s, (h, w))
+    assert rel_err(dx, gx_ref) <= TOL[dtype]
+    dw = ops.conv2d_wgrad(xd, dyd, (k, k, ci, co), s)
+    assert rel_err(dw, gw_ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_conv_dgrad_epilogue(cuda, dtype):
+    """alpha, ReLU mask and addend of the backward-data epilogue."""
+    from stmi import ops
+    n, h, w, ci, co, k, s = 2, 8, 6, 16, 32, 3, 1
+    wt = rnd((k, k, ci, co), 2, 0.1)
+    dy = rnd((n, h, w, co), 4)
+    mask = rnd((n, h, w, ci), 5)
+    add = rnd((n, h, w, ci), 6)
+    xq = torch.zeros((n, h, w, ci), dtype=torch.float64, requires_grad=True)
+    y_ref = O.conv2d_same(xq, q(wt, dtype), s)
+    (gx,) = torch.autograd.grad(y_ref, xq, q(dy, dtype))
+    ref = 0.5 * gx * (q(mask, dtype) > 0) + q(add, dtype)
+    wd = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    got = ops.conv2d_dgrad(dy.to(cuda, dtype), wd, (k, k, ci, co), s, (h, w), relu_mask=mask.to(cuda, dtype),
+                           addend=add.to(cuda, dtype), alpha=0.5)
+    assert rel_err(got, ref) <= TOL[dtype]
+
+
+DECONV_CASES = [(2, 6, 5, 128, 64, 3, 2), (1, 7, 8, 64, 32, 3, 2), (1, 4, 4, 16, 8, 3, 2)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', DECONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_transpose(cuda, dtype, case):
+    from stmi import ops
+    n, h, w, ci, co, k, s = case
+    x = rnd((n, h, w, ci), 1)
+    wt = rnd((k, k, co, ci), 2, 1.0 / np.sqrt(k * k * ci))
+    xq, wq = q(x, dtype).requires_grad_(), q(wt, dtype).requires_grad_()
+    y_ref = O.conv2d_transpose_same(xq, wq, s)
+    dy = rnd(tuple(y_ref.shape), 3)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, (xq, wq), q(dy, dtype))
+    w32 = wt.to(cuda, torch.float32)
+    # the op is the backward-data of a conv whose HWIO weight is W: pack it that way
+    w_fwdpath = ops.pack_conv_weights(w32, ops.PACK_DGRAD, dtype)
+    w_bwdpath = ops.pack_conv_weights(w32, ops.PACK_FWD, dtype)
+    xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
+    y = ops.conv2d_transpose_fwd(xd, w_fwdpath, (k, k, co, ci), s)
+    assert rel_err(y, y_ref) <= TOL[dtype]
+    dx = ops.conv2d_transpose_dgrad(dyd, w_bwdpath, (k, k, co, ci), s)
+    assert rel_err(dx, gx_ref) <= TOL[dtype]
+    dw = ops.conv2d_transpose_wgrad(xd, dyd, (k, k, co, ci), s)
+    assert rel_err(dw, gw_ref) <= TOL[dtype]
+
+
+IN_CASES = [(2, 9, 7, 32, 'relu', False), (2, 16, 16, 128, 'none', True), (1, 12, 10, 3, 'sigmoid', False),
+            (1, 40, 30, 64, 'relu', False), (1, 64, 48, 128, 'relu', False)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', IN_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_instance_norm_fwd_bwd(cuda, dtype, case):
+    from stmi import ops
+    n, h, w, c, act, use_res = case
+    actc = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'sigmoid': ops.ACT_SIGMOID}[act]
+    x = rnd((n, h, w, c), 1) * 3 + 2.0      # non-zero mean exercises the shifted sums
+    scale, shift = rnd((c,), 2) + 1.5, rnd((c,), 3)
+    res = rnd((n, h, w, c), 4) if use_res else None
+    dy = rnd((n, h, w, c), 5)
+    xq = q(x, dtype).requires_grad_()
+    sq, hq = scale.float().double().requires_grad_(), shift.float().double().requires_grad_()
+    z = O.instance_norm(xq, sq, hq)
+    y_ref = {'none': z, 'relu': torch.relu(z), 'sigmoid': torch.sigmoid(z)}[act]
+    if use_res:
+        y_ref = y_ref + q(res, dtype)
+    gx, gs, gh = torch.autograd.grad(y_ref, (xq, sq, hq), q(dy, dtype))
+
+    xd = x.to(cuda, dtype)
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    y, stats, y32 = ops.instance_norm_fwd(xd, sd, hd, actc, residual=None if res is None else res.to(cuda, dtype),
+                                          want_f32=True)
+    assert rel_err(y32, y_ref) <= 1e-3          # fp32 copy is exact up to statistics
+    assert rel_err(y, y_ref) <= TOL[dtype]
+    dscale = torch.zeros(c, device=cuda)
+    dshift = torch.zeros(c, device=cuda)
+    dx = ops.instance_norm_bwd(xd, dy.to(cuda, dtype), stats, sd, hd, dscale, dshift, actc)
+    assert rel_err(dx, gx) <= TOL[dtype]
+    assert rel_err(dscale, gs) <= 1e-3
+    assert rel_err(dshift, gh) <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 8, 8, 64), (1, 7, 5, 16), (1, 127, 3, 8), (2, 5, 6, 3)])
+def test_maxpool(cuda, dtype, shape):
+    from stmi import ops
+    x = torch.relu(rnd(shape, 1))
+    xq = q(x, dtype).requires_grad_()
+    y_ref = O.max_pool_2x2_same(xq)
+    dy = rnd(tuple(y_ref.shape), 2)
+    (gx,) = torch.autograd.grad(y_ref, xq, q(dy, dtype))
+    gx = gx * (xq > 0)       # fused ReLU gradient of the producing layer
+    xd = x.to(cuda, dtype)
+    y = ops.maxpool_fwd(xd)
+    assert rel_err(y, y_ref) == 0.0
+    dx = ops.maxpool_bwd(xd, dy.to(cuda, dtype))
+    assert rel_err(dx, gx) <= 1e-6
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (1, 9, 7, 128), (1, 4, 4, 512), (2, 33, 17, 8), (1, 6, 6, 16)])
+def test_gram_fwd_bwd(cuda, dtype, shape):
+    from stmi import ops
+    n, h, w, c = shape
+    f = rnd(shape, 1)
+    target = rnd((1, c, c), 2)
+    fq = q(f, dtype).requires_grad_()
+    g_ref = O.gram_matrix(fq)
+    loss_ref = ((g_ref - target) ** 2).mean() * 7.0
+    (gf,) = torch.autograd.grad(loss_ref, fq)
+    fd = f.to(cuda, dtype)
+    g = ops.gram_fwd(fd)
+    assert rel_err(g, g_ref) <= (1e-3 if dtype == torch.float32 else 1e-2)
+    loss = torch.zeros(1, device=cuda)
+    ls = 7.0 / (n * c * c)
+    s = ops.gram_mse_fwd_bwd(g, target.to(cuda, torch.float32), loss, ls, 4.0 * ls / (h * w), dtype)
+    assert abs(loss.item() - loss_ref.item()) <= (1e-3 if dtype == torch.float32 else 3e-2) * abs(loss_ref.item())
+    df = torch.ones(shape, device=cuda, dtype=dtype)
+    ops.gram_bwd(fd, s, df, accumulate=True)
+    assert rel_err(df, gf + 1.0) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_losses(cuda, dtype):
+    from stmi import ops
+    a, b = rnd((2, 4, 4, 32), 1), rnd((2, 4, 4, 32), 2)
+    aq = q(a, dtype).requires_grad_()
+    ref = ((aq - q(b, dtype)) ** 2).mean() * 3.0
+    (ga,) = torch.autograd.grad(ref, aq)
+    loss = torch.zeros(1, device=cuda)
+    cnt = a.numel()
+    g = ops.mse_fwd_bwd(a.to(cuda, dtype), b.to(cuda, dtype), loss, 3.0 / cnt, 6.0 / cnt)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert rel_err(g, ga) <= TOL[dtype]
+
+    img = torch.rand((2, 9, 7, 3), dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    iq = img.float().double().requires_grad_()
+    tv_ref = O.total_variation_loss(iq) * 5.0
+    (gi,) = torch.autograd.grad(tv_ref, iq)
+    loss.zero_()
+    gt = ops.tv_loss_fwd_bwd(img.to(cuda, torch.float32), loss, 5.0, dtype)
+    assert abs(loss.item() - tv_ref.item()) <= 1e-4 * abs(tv_ref.item())
+    assert rel_err(gt, gi) <= TOL[dtype]
+    # known answer: a constant image has zero total variation
+    loss.zero_()
+    ops.tv_loss_fwd_bwd(torch.full((1, 5, 5, 3), 0.25, device=cuda), loss, 1.0, dtype)
+    assert loss.item() == 0.0
+
+
+def test_adam_tf1_and_small_ops(cuda):
+    from stmi import ops
+    from oracle import loops as L
+    rng = np.random.default_rng(0)
+    p, g = rng.standard_normal(1000), rng.standard_normal(1000)
+    m, v = np.zeros(1000), np.zeros(1000)
+    pd = torch.tensor(p, device=cuda, dtype=torch.float32)
+    md, vd = torch.zeros(1000, device=cuda), torch.zeros(1000, device=cuda)
+    step = torch.zeros(1, dtype=torch.int32, device=cuda)
+    for t in range(1, 4):
+        # epsilon = 1e-1 (the Gatys setting) makes the TF1 placement of epsilon visible
+        p, m, v = L.adam_tf1(p, g * t, m, v, t, 0.02, 0.99, 0.999, 1e-1)
+        ops.adam_tf1(pd, torch.tensor(g * t, device=cuda, dtype=torch.float32), md, vd, 0.02, 0.99, 0.999, 1e-1,
+                     step_dev=step)
+    assert step.item() == 3
+    assert rel_err(pd, torch.tensor(p)) <= 1e-5
+
+    x = torch.rand((2, 3, 4, 3), device=cuda)
+    mean = torch.tensor([1.0, 2.0, 3.0], device=cuda)
+    y = ops.scale_shift(x, mean, 127.5, torch.float32)
+    assert rel_err(y, O.vgg_preprocess(x.double().cpu(), mean.double().cpu())) <= 1e-6
+    yb = ops.cast(y, torch.bfloat16)
+    assert torch.equal(yb.cpu(), y.cpu().to(torch.bfloat16))
+    assert torch.equal(ops.cast(yb, torch.float32).cpu(), yb.cpu().float())
+    z = torch.tensor([-1.0, 0.5, 2.0], device=cuda)
+    assert ops.clip_(z, 0.0, 1.0).cpu().tolist() == [0.0, 0.5, 1.0]
+
+
+def test_error_reporting(cuda):
+    from stmi import lib, ops
+    x = torch.zeros((1, 4, 4, 3), device=cuda)
+    wp = torch.zeros(ops.packed_elems(3, 3, 3, 8, ops.PACK_FWD), device=cuda)
+    with pytest.raises(lib.StmiError, match='stride 1'):
+        ops.conv2d_fwd(x, wp, (3, 3, 3, 8), 2)
+    with pytest.raises(lib.StmiError, match='no CPU fallback'):
+        ops.maxpool_fwd(torch.zeros((1, 2, 2, 8)))
