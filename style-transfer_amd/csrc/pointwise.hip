@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
         float v = 0.f;
         if (row < c && col < c) {
             const float d = g[((long)b * c + row) * c + col] - target[(long)row * c + col];
+            const float dt = g[((long)b * c + col) * c + row] - target[(long)col * c + row];
             acc += d * d;
-            v = grad_scale * d;
+            v = grad_scale * 0.5f * (d + dt);  // (dG + dG^T)/2: exact also for a non-symmetric target
         }
         sout[i] = from_f32<T>(v);
     }

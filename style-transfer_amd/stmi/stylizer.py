@@ -1,0 +1,205 @@
+"""Static executor for the 3-5-3 stylizer (reference full_graph_stylizer_network.py:42-82).
+
+All parameters live in ONE flat fp32 buffer in the reference's variable creation
+order (per block: W, IN shift, IN scale; model_utilities.py:236-239, :284-285),
+so the optimizer and the data-parallel all-reduce each touch a single tensor.
+Activations are NHWC in the compute dtype; every buffer is allocated once, so a
+forward/backward pass is a fixed list of kernel launches that can be captured
+in a HIP graph.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+# (kind, cout, k, stride, act, residual-role)
+#   residual-role: 'a' = first conv of a residual block, 'b' = second (adds the block input)
+_BLOCKS = (
+    [('conv', 32, 9, 1, ops.ACT_RELU, None), ('conv', 64, 3, 2, ops.ACT_RELU, None), ('conv', 128, 3, 2, ops.ACT_RELU, None)]
+    + [('conv', 128, 3, 1, ops.ACT_RELU, 'a'), ('conv', 128, 3, 1, ops.ACT_NONE, 'b')] * 5
+    + [('deconv', 64, 3, 2, ops.ACT_RELU, None), ('deconv', 32, 3, 2, ops.ACT_RELU, None),
+       ('conv', 3, 9, 1, ops.ACT_SIGMOID, None)]
+)
+
+
+def param_shapes(cin=3):
+    """The 48 tensor shapes in creation order."""
+    shapes, c = [], cin
+    for kind, co, k, _s, _a, _r in _BLOCKS:
+        shapes.append((k, k, co, c) if kind == 'deconv' else (k, k, c, co))
+        shapes += [(co,), (co,)]
+        c = co
+    return shapes
+
+
+def init_params(seed=1, cin=3):
+    """Truncated normal (sigma .1, resampled beyond 2 sigma) for W, zeros for shift,
+    ones for scale -- the initialisers of model_utilities.py:231-232, :284-285.
+    Seeded NumPy stream; not bit-equal to tf.truncated_normal(seed=1)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, shp in enumerate(param_shapes(cin)):
+        if len(shp) == 4:
+            a = rng.standard_normal(shp)
+            bad = np.abs(a) > 2.0
+            while bad.any():
+                a[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(a) > 2.0
+            out.append((a * 0.1).astype(np.float32))
+        elif i % 3 == 1:
+            out.append(np.zeros(shp, np.float32))
+        else:
+            out.append(np.ones(shp, np.float32))
+    return out
+
+
+class _Block:
+    pass
+
+
+class StylizerNet:
+    def __init__(self, batch, height, width, device, dtype=torch.float32, params=None, seed=1, training=False):
+        self.n, self.h, self.w = batch, height, width
+        self.device, self.dtype, self.training = device, dtype, training
+        shapes = param_shapes()
+        sizes = [int(np.prod(s)) for s in shapes]
+        self.num_params = sum(sizes)
+        self.flat = torch.empty(self.num_params, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(self.num_params, dtype=torch.float32, device=device) if training else None
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        self.views = [self.flat[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(len(shapes))]
+        self.grad_views = ([self.flat_grad[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(len(shapes))]
+                           if training else None)
+        self.offsets = offs
+        self.load_params(init_params(seed) if params is None else params)
+
+        self.x_in = torch.empty((batch, height, width, 3), dtype=dtype, device=device)
+        self.blocks = []
+        h, w, c = height, width, 3
+        ws_floats = 0
+        for i, (kind, co, k, s, act, role) in enumerate(_BLOCKS):
+            b = _Block()
+            b.kind, b.co, b.k, b.s, b.act, b.role, b.ci = kind, co, k, s, act, role, c
+            b.in_h, b.in_w = h, w
+            if kind == 'deconv':
+                b.kshape = (k, k, co, c)
+                b.out_h, b.out_w = h * s, w * s
+                fwd_mode, bwd_mode = ops.PACK_DGRAD, ops.PACK_FWD
+                pk = (k, k, co, c)
+            else:
+                b.kshape = (k, k, c, co)
+                b.out_h, b.out_w = ops.same_out(h, s), ops.same_out(w, s)
+                fwd_mode, bwd_mode = ops.PACK_FWD, ops.PACK_DGRAD
+                pk = (k, k, c, co)
+            b.fwd_mode, b.bwd_mode = fwd_mode, bwd_mode
+            b.W, b.shift, b.scale = self.views[3 * i], self.views[3 * i + 1], self.views[3 * i + 2]
+            b.wp_fwd = torch.empty(ops.packed_elems(*pk, fwd_mode), dtype=dtype, device=device)
+            b.wp_bwd = (torch.empty(ops.packed_elems(*pk, bwd_mode), dtype=dtype, device=device)
+                        if training and i > 0 else None)
+            oshape = (batch, b.out_h, b.out_w, co)
+            b.stats = torch.empty((batch, co, 2), dtype=torch.float32, device=device)
+            if training:
+                b.dW, b.dshift, b.dscale = (self.grad_views[3 * i], self.grad_views[3 * i + 1],
+                                            self.grad_views[3 * i + 2])
+                b.conv_out = torch.empty(oshape, dtype=dtype, device=device)
+                b.y = torch.empty(oshape, dtype=dtype, device=device)
+            ws_floats = max(ws_floats, batch * 64 * 2 * co)
+            self.blocks.append(b)
+            h, w, c = b.out_h, b.out_w, co
+        self.out_f32 = torch.empty((batch, h, w, 3), dtype=torch.float32, device=device)
+        self.ws = torch.empty(ws_floats, dtype=torch.float32, device=device)
+        if not training:
+            # inference: blocks share a small pool of buffers sized for the largest activation
+            biggest = max(batch * b.out_h * b.out_w * b.co for b in self.blocks)
+            self._pool = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(4)]
+        else:
+            biggest = max(batch * b.out_h * b.out_w * b.co for b in self.blocks)
+            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(4)]
+        self.repack()
+
+    # ------------------------------------------------------------ parameters
+    def load_params(self, params):
+        assert len(params) == len(self.views), 'expected %d tensors in creation order' % len(self.views)
+        for v, p in zip(self.views, params):
+            t = torch.as_tensor(np.asarray(p), dtype=torch.float32)
+            assert tuple(t.shape) == tuple(v.shape), (tuple(t.shape), tuple(v.shape))
+            v.copy_(t)
+
+    def export_params(self):
+        return [v.detach().cpu().numpy().copy() for v in self.views]
+
+    def repack(self):
+        """Refreshes the K-contiguous weight copies after the fp32 masters changed."""
+        for b in self.blocks:
+            ops.pack_conv_weights(b.W, b.fwd_mode, self.dtype, out=b.wp_fwd)
+            if b.wp_bwd is not None:
+                ops.pack_conv_weights(b.W, b.bwd_mode, self.dtype, out=b.wp_bwd)
+
+    # --------------------------------------------------------------- forward
+    def _view(self, buf, b):
+        n = self.n * b.out_h * b.out_w * b.co
+        return buf[:n].view(self.n, b.out_h, b.out_w, b.co)
+
+    def forward(self, x_f32):
+        """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32)."""
+        ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
+        cur = self.x_in
+        skip = None
+        last = len(self.blocks) - 1
+        for i, b in enumerate(self.blocks):
+            if self.training:
+                conv_out, y = b.conv_out, b.y
+            else:
+                # rotate through the pool, never overwriting the live skip tensor
+                free = [p for p in self._pool if p.data_ptr() not in
+                        (cur.data_ptr(), None if skip is None else skip.data_ptr())]
+                conv_out, y = self._view(free[0], b), self._view(free[1], b)
+            if b.kind == 'deconv':
+                ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+            else:
+                ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+            if b.role == 'a':
+                skip = cur
+            ops.instance_norm_fwd(conv_out, b.scale, b.shift, b.act, residual=skip if b.role == 'b' else None,
+                                  want_f32=(i == last), ws=self.ws, out=y, stats=b.stats,
+                                  out_f32=self.out_f32 if i == last else None)
+            if b.role == 'b':
+                skip = None
+            cur = y
+        return self.out_f32
+
+    # -------------------------------------------------------------- backward
+    def backward(self, d_out):
+        """d_out: gradient w.r.t. the stylized image, compute dtype [n,h,w,3].
+        Parameter gradients are written (W) or added (shift/scale) into
+        self.flat_grad, which the caller zeroes once per step."""
+        assert self.training
+        g = d_out
+        pending_skip = None  # gradient flowing along a residual connection
+        bufs = self._g
+        for i in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[i]
+            x_in = self.blocks[i - 1].y if i > 0 else self.x_in
+            free = [p for p in bufs if p.data_ptr() not in
+                    (g.data_ptr(), None if pending_skip is None else pending_skip.data_ptr())]
+            dconv = self._view(free[0], b)
+            if b.role == 'b':
+                pending_skip = g  # d(block input) receives d(block output) unchanged
+            ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act,
+                                  ws=self.ws, out=dconv)
+            if b.kind == 'deconv':
+                ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
+            else:
+                ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
+            if i == 0:
+                break
+            n_in = self.n * b.in_h * b.in_w * b.ci
+            dx = free[1][:n_in].view(self.n, b.in_h, b.in_w, b.ci)
+            addend = pending_skip if b.role == 'a' else None
+            if b.kind == 'deconv':
+                ops.conv2d_transpose_dgrad(dconv, b.wp_bwd, b.kshape, b.s, addend=addend, out=dx)
+            else:
+                ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx)
+            if b.role == 'a':
+                pending_skip = None
+            g = dx

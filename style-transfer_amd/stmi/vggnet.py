@@ -1,0 +1,215 @@
+"""VGG19 feature extractor and perceptual-loss executor.
+
+Restates what the reference builds with build_vgg_network_replicate_from_mat
+(vgg.py:60-108) and StyleTransfer.total_loss (model_utilities.py:391-399) as a
+fixed list of HIP kernel launches: preprocessing, 14 frozen 3x3 convolutions
+through conv5_2 with fused bias+ReLU, four SAME max-pools, five Gram matrices
+of the PRE-ReLU conv1_1..conv5_1 outputs, the content tap at pre-ReLU conv5_2,
+and the full backward to the input image (data gradients only; VGG weights are
+constants in the reference graph).
+"""
+import torch
+
+from . import ops
+
+LAYER_NAMES = [
+    'conv1_1', 'relu1_1', 'conv1_2', 'relu1_2', 'pool1',
+    'conv2_1', 'relu2_1', 'conv2_2', 'relu2_2', 'pool2',
+    'conv3_1', 'relu3_1', 'conv3_2', 'relu3_2', 'conv3_3', 'relu3_3', 'conv3_4', 'relu3_4', 'pool3',
+    'conv4_1', 'relu4_1', 'conv4_2', 'relu4_2', 'conv4_3', 'relu4_3', 'conv4_4', 'relu4_4', 'pool4',
+    'conv5_1', 'relu5_1', 'conv5_2', 'relu5_2', 'conv5_3', 'relu5_3', 'conv5_4', 'relu5_4',
+]
+STYLE_CONV_TAPS = ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+CONTENT_CONV_TAP = 'conv5_2'
+STYLE_RELU_TAPS = ['relu1_1', 'relu2_1', 'relu3_1', 'relu4_1', 'relu5_1']
+CONTENT_RELU_TAP = 'relu5_2'
+
+
+class _Layer:
+    pass
+
+
+class VggFeatures:
+    """One weight set, any number of static-shape 'replicas' (see replica())."""
+
+    def __init__(self, weights, mean, device, dtype=torch.float32, with_backward=True, last='conv5_2'):
+        """weights: dict conv name -> (W fp32 HWIO [3,3,ci,co], bias [co]) in the orientation
+        vgg.py:92-95 hands to conv2d; mean: 3 floats subtracted after the *255/2 scaling."""
+        self.device, self.dtype = device, dtype
+        self.mean = torch.as_tensor(mean, dtype=torch.float32).reshape(3).to(device).contiguous()
+        self.convs = {}
+        names = LAYER_NAMES[:LAYER_NAMES.index(last) + 1]
+        self.names = names
+        for name in names:
+            if not name.startswith('conv'):
+                continue
+            w, b = weights[name]
+            w = torch.as_tensor(w, dtype=torch.float32).to(device).contiguous()
+            L = _Layer()
+            L.kshape = tuple(w.shape)
+            L.bias = torch.as_tensor(b, dtype=torch.float32).reshape(-1).to(device).contiguous()
+            L.wp_fwd = ops.pack_conv_weights(w, ops.PACK_FWD, dtype)
+            L.wp_bwd = ops.pack_conv_weights(w, ops.PACK_DGRAD, dtype) if with_backward else None
+            self.convs[name] = L
+
+    def replica(self, batch, height, width, keep_for_backward=False, relu_taps=False):
+        return VggReplica(self, batch, height, width, keep_for_backward, relu_taps)
+
+
+class VggReplica:
+    """Static buffers for one input shape."""
+
+    def __init__(self, net, batch, height, width, keep, relu_taps=False):
+        self.net, self.n, self.h, self.w, self.keep, self.relu_taps = net, batch, height, width, keep, relu_taps
+        dev, dt = net.device, net.dtype
+        self.style_names = STYLE_RELU_TAPS if relu_taps else STYLE_CONV_TAPS
+        self.content_name = CONTENT_RELU_TAP if relu_taps else CONTENT_CONV_TAP
+        assert not (keep and relu_taps), 'the backward pass is built for the pre-ReLU taps of the training path'
+        self.x_pre = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+        self.act = {}      # name -> output buffer of that layer (post-ReLU for relu layers)
+        self.pre = {}      # conv name -> pre-ReLU output where it is tapped
+        self.shape = {}
+        h, w, c = height, width, 3
+        scratch_need = 0
+        for name in net.names:
+            if name.startswith('conv'):
+                c = net.convs[name].kshape[3]
+            elif name.startswith('pool'):
+                h, w = (h + 1) // 2, (w + 1) // 2
+            self.shape[name] = (batch, h, w, c)
+            scratch_need = max(scratch_need, batch * h * w * c)
+        tapped_pre = set(STYLE_CONV_TAPS) if not relu_taps else set()
+        if keep:
+            for name in net.names:
+                if name.startswith('conv'):
+                    if name in tapped_pre:
+                        self.pre[name] = torch.empty(self.shape[name], dtype=dt, device=dev)
+                elif name.startswith('relu') or name.startswith('pool'):
+                    self.act[name] = torch.empty(self.shape[name], dtype=dt, device=dev)
+            self._gbuf = [torch.empty(scratch_need, dtype=dt, device=dev) for _ in range(2)]
+        else:
+            self._scratch = [torch.empty(scratch_need, dtype=dt, device=dev) for _ in range(3)]
+        self.grams = [torch.empty((batch, self.shape[nm][3], self.shape[nm][3]), dtype=torch.float32, device=dev)
+                      for nm in self.style_names]
+        self.content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
+        if keep:
+            self.s_packed = [torch.empty(ops.gram_packed_elems(batch, self.shape[nm][3]), dtype=dt, device=dev)
+                             for nm in self.style_names]
+            self.d_content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
+            self.d_image = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+            self.tv_grad = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+
+    def _buf(self, pool, shape, avoid):
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        for p in pool:
+            if all(a is None or p.data_ptr() != a.data_ptr() for a in avoid):
+                return p[:n].view(shape)
+        raise RuntimeError('no free scratch buffer')
+
+    # --------------------------------------------------------------- forward
+    def forward(self, x_f32):
+        """Fills self.grams (5 x fp32 [n,c,c]) and self.content from an fp32 image batch in [0,1]."""
+        net = self.net
+        ops.scale_shift(x_f32, net.mean, 255.0 / 2.0, net.dtype, out=self.x_pre)
+        cur = self.x_pre
+        names = net.names
+        i = 0
+        while i < len(names):
+            name = names[i]
+            shape = self.shape[name]
+            if name.startswith('conv'):
+                L = net.convs[name]
+                has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
+                tap_pre = (not self.relu_taps) and (name in STYLE_CONV_TAPS or name == CONTENT_CONV_TAP)
+                if has_relu:
+                    rname = names[i + 1]
+                    if self.keep:
+                        y = self.act[rname]
+                        pre = self.pre.get(name)
+                    else:
+                        y = self._buf(self._scratch, shape, (cur,))
+                        pre = self._buf(self._scratch, shape, (cur, y)) if tap_pre else None
+                    if pre is not None:
+                        ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=True, want_pre=True, out=y, out_pre=pre)
+                    else:
+                        ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=True, out=y)
+                    self._tap(name, pre)
+                    self._tap(rname, y)
+                    cur = y
+                    i += 2
+                    continue
+                # last layer of the truncated network: no ReLU follows
+                y = self.content if name == self.content_name else self._buf(self._scratch, shape, (cur,))
+                ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=False, out=y)
+                self._tap(name, y)
+                cur = y
+            elif name.startswith('pool'):
+                y = self.act[name] if self.keep else self._buf(self._scratch, shape, (cur,))
+                ops.maxpool_fwd(cur, out=y)
+                cur = y
+            i += 1
+        return self.grams, self.content
+
+    def _tap(self, name, tensor):
+        if tensor is None:
+            return
+        if name in self.style_names:
+            ops.gram_fwd(tensor, out=self.grams[self.style_names.index(name)])
+        if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
+            self.content.copy_(tensor)
+
+    # -------------------------------------------------------- loss + backward
+    def loss_and_grad(self, x_f32, style_targets, content_target, style_weight, content_weight, tv_weight, losses):
+        """Runs forward on x_f32, ADDS [total, style, content, tv] into `losses` (fp32 [4], device,
+        zeroed by the caller) and returns d(total)/d(x) in the compute dtype.
+
+        style_targets: 5 fp32 [c,c] (or [1,c,c]) Grams, content_target: tensor shaped like the content tap."""
+        assert self.keep
+        net, n = self.net, self.n
+        self.forward(x_f32)
+        l_style, l_content, l_tv = losses[1:2], losses[2:3], losses[3:4]
+        # style: sum_l mean((G_l - T_l)^2) * w / len(content outputs)   (model_utilities.py:396)
+        for li, nm in enumerate(self.style_names):
+            c = self.shape[nm][3]
+            hw = self.shape[nm][1] * self.shape[nm][2]
+            ls = style_weight / float(n * c * c)
+            ops.gram_mse_fwd_bwd(self.grams[li], style_targets[li], l_style, ls, 4.0 * ls / hw, net.dtype,
+                                 out=self.s_packed[li])
+        cnt = self.content.numel()
+        ops.mse_fwd_bwd(self.content, content_target, l_content, content_weight / cnt, 2.0 * content_weight / cnt,
+                        out=self.d_content)
+        ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+
+        # backward through the truncated VGG; g is always the gradient w.r.t. a conv's pre-ReLU output
+        names = net.names
+        g = self.d_content
+        idx = len(names) - 1
+        while idx >= 0:
+            name = names[idx]
+            if name.startswith('conv'):
+                if name in self.style_names:
+                    li = self.style_names.index(name)
+                    ops.gram_bwd(self.pre[name], self.s_packed[li], g, accumulate=True)
+                L = net.convs[name]
+                in_name = names[idx - 1] if idx > 0 else None
+                h, w = (self.shape[in_name][1], self.shape[in_name][2]) if in_name else (self.h, self.w)
+                if in_name is None:
+                    # d(preprocess)/dx = 255/2; the TV gradient joins here
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), alpha=255.0 / 2.0, addend=self.tv_grad,
+                                     out=self.d_image)
+                    g = self.d_image
+                elif in_name.startswith('relu'):
+                    dx = self._buf(self._gbuf, self.shape[in_name], (g,))
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=self.act[in_name], out=dx)
+                    g = dx
+                    idx -= 1  # the ReLU is folded into the mask
+                else:  # pool output feeds this conv
+                    dpool = self._buf(self._gbuf, self.shape[in_name], (g,))
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), out=dpool)
+                    relu_name = names[idx - 2]
+                    dx = self._buf(self._gbuf, self.shape[relu_name], (dpool,))
+                    ops.maxpool_bwd(self.act[relu_name], dpool, out=dx)
+                    g = dx
+                    idx -= 2
+            idx -= 1
+        return self.d_image
