@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stylizer training step, batch 4 x 256 x 256 per GPU, VGG19
+perceptual + Gram style loss (starry_night weights), synthetic data.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  A step = stylizer forward, VGG19 forward on the
+content batch and on the stylized batch, Gram + content + TV losses, the full
+backward, (N > 1: bucketed RCCL gradient all-reduce overlapped with backward),
+TF1 Adam and weight re-packing.  Inputs are resident in HBM before the timed
+region.  Other workloads (--workload infer1080p | gatys) print the same kind of
+line for the other BASELINE.json configurations.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'style-transfer_amd')]
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense MFMA peaks, MI355X
+STARRY = (1e-2, 1e4, 1e8)                      # style, content, tv weights of 'starry_night_transfer'
+
+
+def synthetic_vgg(seed=7):
+    """Real-shape VGG19 weights: He-normal kernels, zero bias (values do not affect timing)."""
+    from stmi.vggnet import LAYER_NAMES
+    plan = {'1': 64, '2': 128, '3': 256, '4': 512, '5': 512}
+    rng = np.random.default_rng(seed)
+    out, ci = {}, 3
+    for name in LAYER_NAMES:
+        if name.startswith('conv'):
+            co = plan[name[4]]
+            w = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+            out[name] = (w, np.zeros(co, np.float32))
+            ci = co
+    return out
+
+
+def dist_setup(gpus):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if gpus > 1 and world == 1:
+        raise SystemExit('--gpus %d needs one process per GPU: launch with python -m torch.distributed.run '
+                         '--nproc-per-node %d' % (gpus, gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    return world, rank, torch.device('cuda', local)
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, device):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def timed_steps(step_fn, steps, warmup, world, device):
+    for _ in range(warmup):
+        step_fn()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier(world)
+    return max_over_ranks(time.perf_counter() - t0, world, device)
+
+
+def roofline_train(trainer, dtype_name):
+    """Per-launch HIP-event timing of the convolution kernels inside one eager training
+    step; returns the roofline object of the instantiation with the largest total time."""
+    from stmi import ops
+    trainer_graph = trainer.use_graph
+    trainer.use_graph = False
+    acc = {}
+    for rep in range(3):
+        ops.PROFILE = []
+        trainer.step()
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue  # first eager pass warms caches
+        for name, flops, e0, e1 in ops.PROFILE:
+            a = acc.setdefault(name, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+    ops.PROFILE = None
+    trainer.use_graph = trainer_graph
+    name, (flops, secs, launches) = max(acc.items(), key=lambda kv: kv[1][1])
+    achieved = flops / secs / 1e12
+    peak = PEAK_TFLOPS[dtype_name]
+    return {
+        'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': name,
+        'launches_per_step': launches // 2, 'avg_launch_us': round(secs / launches * 1e6, 2),
+        'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
+        'all_conv_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'share_of_conv_time':
+                                 round(v[1] / sum(x[1] for x in acc.values()), 3)} for k, v in acc.items()},
+    }
+
+
+def cpu_baseline_train(batch_np, style_np, params, vggw, weights, budget_s=25.0):
+    """The oracle (torch-CPU fp32 restatement of the reference step) timed on the host cores."""
+    from oracle import tf_ops as O
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))))
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    P = [f32(p).requires_grad_() for p in params]
+    W = {k: (f32(w), f32(b)) for k, (w, b) in vggw.items()}
+    mean = torch.zeros(3)
+    m = [torch.zeros_like(p) for p in P]
+    v = [torch.zeros_like(p) for p in P]
+    with torch.no_grad():
+        targets, _ = O.vgg_taps(O.vgg_preprocess(f32(style_np[:, :256, :256]), mean), W)
+    x = f32(batch_np)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        loss, *_ = O.train_step_loss(x, P, W, targets, mean, *weights)
+        grads = torch.autograd.grad(loss, P)
+        with torch.no_grad():
+            O.adam_tf1_step(P, grads, m, v, done + 1)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 8:
+            break
+    return {'value': round(batch_np.shape[0] * done / el, 4), 'unit': 'train img/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': '%d full training steps of the same 4x256x256 workload (torch-CPU fp32 '
+            'restatement of the reference step; TensorFlow itself is not installable here)' % done}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
+    ap.add_argument('--workload', choices=['train', 'infer1080p', 'gatys'], default='train')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    world, rank, device = dist_setup(args.gpus)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    from stmi.stylizer import StylizerNet, init_params
+    from stmi.trainer import GatysOptimizer, StyleTrainer
+
+    rng = np.random.default_rng(1234 + rank)
+    line = {'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True,
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic'}
+
+    if args.workload == 'train':
+        B = args.batch or 4
+        params = init_params(seed=1)
+        vggw = synthetic_vgg()
+        batch = rng.random((B, 256, 256, 3), dtype=np.float32)
+        style = np.random.default_rng(99).random((1, 1014, 1280, 3), dtype=np.float32)
+        tr = StyleTrainer(B, 256, 256, device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype, params=params,
+                          world_size=world, use_graph=not args.no_graph)
+        tr.set_style_image(torch.from_numpy(style))
+        tr.batch_in.copy_(torch.from_numpy(batch))
+        torch.cuda.synchronize()
+        secs = timed_steps(lambda: tr.step(), args.steps, args.warmup, world, device)
+        losses = tr.read_losses()
+        line.update({'metric': 'train img/s (VGG19 Gram loss)', 'unit': 'img/s',
+                     'value': round(B * world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
+                     'scaling': 'weak',
+                     'config': {'workload': 'stylizer training step, batch 4x256x256 per GPU, VGG19 perceptual + Gram '
+                                'style loss (starry_night_transfer weights), synthetic COCO-shaped batch',
+                                'global_batch': B * world, 'image': '256x256', 'parallelism': 'dp%d' % world,
+                                'hip_graph': not args.no_graph},
+                     'final_losses': {'total': float(losses[0]), 'style': float(losses[1]),
+                                      'content': float(losses[2]), 'tv': float(losses[3])}})
+        if rank == 0 and world == 1:
+            if not args.no_roofline:
+                line['roofline'] = roofline_train(tr, args.dtype)
+            if not args.no_cpu_baseline:
+                line['cpu_baseline'] = cpu_baseline_train(batch, style, params, vggw, STARRY)
+    elif args.workload == 'infer1080p':
+        B = args.batch or 16
+        net = StylizerNet(B, 1080, 1920, device, dtype, params=init_params(seed=1))
+        frames = torch.from_numpy(rng.random((B, 1080, 1920, 3), dtype=np.float32)).to(device)
+        torch.cuda.synchronize()
+        secs = timed_steps(lambda: net.forward(frames), args.steps, args.warmup, world, device)
+        line.update({'metric': 'stylized img/s @1080p', 'unit': 'img/s',
+                     'value': round(B * world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
+                     'scaling': 'weak',
+                     'config': {'workload': 'batched 1920x1080 stylizer inference, %d frames per GPU, frames sharded '
+                                'across GPUs with no collective' % B, 'global_batch': B * world}})
+    else:
+        vggw = synthetic_vgg()
+        content = rng.random((1, 512, 512, 3), dtype=np.float32)
+        style = np.random.default_rng(99).random((1, 512, 512, 3), dtype=np.float32)
+        opt = GatysOptimizer(torch.from_numpy(content), device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype,
+                             use_graph=not args.no_graph)
+        opt.set_style_image(torch.from_numpy(style))
+        secs = timed_steps(opt.step, args.steps, args.warmup, world, device)
+        line.update({'metric': 'Gatys steps/s (512x512, VGG19 Gram + content loss)', 'unit': 'steps/s',
+                     'value': round(world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
+                     'scaling': 'weak',
+                     'config': {'workload': 'Gatys iterative optimisation of one 512x512 image; replicas only'}})
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -48,6 +48,10 @@ const char* stmi_last_error(void);
 /* writes e.g. "gfx950:sramecc+:xnack-" of the current device */
 int stmi_device_arch(char* buf, int buflen);
 
+/* Profiling aid: the name a profiler shows for the kernel instantiation that a stride-1
+ * convolution (forward or backward-data) writing `out_channels` x `out_pixels` launches. */
+int stmi_conv_kernel_name(int out_channels, long out_pixels, int dtype, char* buf, int buflen);
+
 /* ---- weight packing ---------------------------------------------------- */
 /* Weights live as fp32 HWIO [kh,kw,ci,co] (the layout of the reference's
  * tf.Variable, model_utilities.py:236, and of the transposed .mat kernels,

@@ -21,6 +21,7 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 // implemented in the kernel translation units
+void conv_kernel_name(int rows, long pixels, int dtype, char* buf, int buflen);
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s);
@@ -83,6 +84,13 @@ int stmi_device_arch(char* buf, int buflen) {
     rc = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
     if (rc) return rc;
     snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return STMI_OK;
+}
+
+int stmi_conv_kernel_name(int out_channels, long out_pixels, int dtype, char* buf, int buflen) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(buf && buflen > 0 && out_channels > 0 && out_pixels > 0, "conv_kernel_name: bad arguments");
+    conv_kernel_name(out_channels, out_pixels, dtype, buf, buflen);
     return STMI_OK;
 }
 

@@ -266,30 +266,45 @@ static int launch_cfg(const ConvGemmParams& p, long Mz, int nz, hipStream_t s) {
     return STMI_OK;
 }
 
+// tile configuration for a problem: 0 = 128co x 128pix, 1 = 64x64, 2 = 64x256, 3 = 32x256, 4 = 16x256
+static int pick_cfg(int rows, long Mz, int nz) {
+    if (rows % 128 == 0) {
+        const long blocks = (long)ceil_div(Mz, 128) * (rows / 128) * nz;
+        return blocks >= 384 ? 0 : 1;
+    }
+    if (rows % 64 == 0) {
+        const long blocks = (long)ceil_div(Mz, 256) * (rows / 64) * nz;
+        return blocks >= 384 ? 2 : 1;
+    }
+    return rows % 32 == 0 ? 3 : 4;
+}
+
 template <typename T>
 static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
     const int nz = batched ? p.N : 1;
     if (Mz <= 0) return STMI_OK;
-    const int rows = p.co_pad;
-    if (rows % 128 == 0) {
-        const long blocks = (long)ceil_div(Mz, 128) * (rows / 128) * nz;
-        if (blocks >= 384) return launch_cfg<T, 4, 4, 2, 2>(p, Mz, nz, s);
-        return launch_cfg<T, 2, 2, 2, 2>(p, Mz, nz, s);
+    switch (pick_cfg(p.co_pad, Mz, nz)) {
+        case 0: return launch_cfg<T, 4, 4, 2, 2>(p, Mz, nz, s);
+        case 1: return launch_cfg<T, 2, 2, 2, 2>(p, Mz, nz, s);
+        case 2: return launch_cfg<T, 4, 4, 1, 4>(p, Mz, nz, s);
+        case 3: return launch_cfg<T, 2, 4, 1, 4>(p, Mz, nz, s);
+        default: return launch_cfg<T, 1, 4, 1, 4>(p, Mz, nz, s);
     }
-    if (rows % 64 == 0) {
-        const long blocks = (long)ceil_div(Mz, 256) * (rows / 64) * nz;
-        if (blocks >= 384) return launch_cfg<T, 4, 4, 1, 4>(p, Mz, nz, s);
-        return launch_cfg<T, 2, 2, 2, 2>(p, Mz, nz, s);
-    }
-    if (rows % 32 == 0) return launch_cfg<T, 2, 4, 1, 4>(p, Mz, nz, s);
-    return launch_cfg<T, 1, 4, 1, 4>(p, Mz, nz, s);
 }
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t s) {
     if (dtype == STMI_BF16) return launch_typed<bf16_t>(p, s);
     return launch_typed<float>(p, s);
+}
+
+// Name (as a profiler prints it) of the kernel instantiation a stride-1 conv forward or
+// backward-data of this geometry launches.
+void conv_kernel_name(int rows, long pixels, int dtype, char* buf, int buflen) {
+    static const char* cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
+    snprintf(buf, buflen, "void stmi::conv_gemm_kernel<%s, %s>(stmi::ConvGemmParams)",
+             dtype == STMI_BF16 ? "__bf16" : "float", cfg[pick_cfg(packed_rows(rows), pixels, 1)]);
 }
 
 // rows of a packed weight set are padded so that every block tile height divides them

@@ -44,6 +44,38 @@ def same_out(size, stride):
     return -(-size // stride)
 
 
+# Optional per-launch timing for bench.py's roofline leg: when PROFILE is a list, every
+# stride-1 conv forward / backward-data launch appends (kernel name, algorithmic flops,
+# start event, end event).  The events are recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
+def _kernel_name(out_channels, out_pixels, dtype_code):
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    _lib.call('stmi_conv_kernel_name', out_channels, out_pixels, dtype_code, buf, 256)
+    return buf.value.decode()
+
+
+class _Timed:
+    def __init__(self, out_channels, out_pixels, k_total, dtype_code, stride):
+        self.on = PROFILE is not None and stride == 1
+        if self.on:
+            self.name = _kernel_name(out_channels, out_pixels, dtype_code)
+            self.flops = 2.0 * out_channels * out_pixels * k_total
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+
+
 # ---------------------------------------------------------------- weights
 def packed_elems(kh, kw, ci, co, mode):
     return _lib.load().stmi_conv_packed_elems(kh, kw, ci, co, mode)
@@ -76,8 +108,9 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
         pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', x.dtype, oshape)
     if bias is not None:
         _chk(bias, 'bias', torch.float32, (co,))
-    _lib.call('stmi_conv2d_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
-              n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x), _stream())
+    with _Timed(co, n * oshape[1] * oshape[2], kh * kw * ci, _dt(x), stride):
+        _lib.call('stmi_conv2d_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
+                  n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x), _stream())
     return (y, pre) if want_pre else y
 
 
@@ -93,8 +126,9 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
     for t, nm in ((relu_mask, 'relu_mask'), (addend, 'addend')):
         if t is not None:
             _chk(t, nm, dy.dtype, oshape)
-    _lib.call('stmi_conv2d_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
-              _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
+    with _Timed(ci, n * h * w, kh * kw * co, _dt(dy), stride):
+        _lib.call('stmi_conv2d_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
+                  _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
     return dx
 
 

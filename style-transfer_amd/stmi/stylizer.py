@@ -169,15 +169,23 @@ class StylizerNet:
         return self.out_f32
 
     # -------------------------------------------------------------- backward
-    def backward(self, d_out):
+    def backward(self, d_out, hi=None, lo=0):
         """d_out: gradient w.r.t. the stylized image, compute dtype [n,h,w,3].
         Parameter gradients are written (W) or added (shift/scale) into
-        self.flat_grad, which the caller zeroes once per step."""
+        self.flat_grad, which the caller zeroes once per step.
+
+        The pass can be cut into block ranges so that a data-parallel caller can
+        start reducing the gradients of finished blocks: backward(d_out, hi=15,
+        lo=11) then backward(None, hi=10, lo=7) ... continue where the previous
+        call stopped."""
         assert self.training
-        g = d_out
-        pending_skip = None  # gradient flowing along a residual connection
+        if hi is None:
+            hi = len(self.blocks) - 1
+        if d_out is not None:
+            self._bstate = (d_out, None)
+        g, pending_skip = self._bstate  # pending_skip: gradient flowing along a residual connection
         bufs = self._g
-        for i in range(len(self.blocks) - 1, -1, -1):
+        for i in range(hi, lo - 1, -1):
             b = self.blocks[i]
             x_in = self.blocks[i - 1].y if i > 0 else self.x_in
             free = [p for p in bufs if p.data_ptr() not in
@@ -203,3 +211,8 @@ class StylizerNet:
             if b.role == 'a':
                 pending_skip = None
             g = dx
+        self._bstate = (g, pending_skip)
+
+    def param_range(self, hi, lo):
+        """[start, end) of the flat parameter/gradient buffer covered by blocks lo..hi."""
+        return int(self.offsets[3 * lo]), int(self.offsets[3 * (hi + 1)])

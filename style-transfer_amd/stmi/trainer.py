@@ -1,0 +1,245 @@
+"""Training-step and Gatys-step executors.
+
+StyleTrainer restates the per-step data flow of train_style_network
+(reference full_graph_stylizer_network.py:198-216): content targets from the VGG
+replica fed with the batch, stylizer forward, VGG + Gram + losses on the
+stylized batch, backward to the 48 stylizer variables, TF1 Adam.  GatysOptimizer
+restates normal_style_transfer (full_graph_stylizer_network.py:257-279,
+:308-329): the image itself is the variable.
+
+The kernel sequence of a step is static, so it is captured once into HIP graphs
+and replayed.  With data parallelism the stylizer backward is cut into block
+ranges; after each range the gradient bucket it completed is all-reduced (RCCL)
+while the next range runs.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .stylizer import StylizerNet
+from .vggnet import VggFeatures
+
+# block ranges (hi..lo) of the stylizer backward; one all-reduce bucket each
+BWD_SEGMENTS = [(15, 11), (10, 7), (6, 0)]
+
+
+class GradBuckets:
+    """Bucketed sum-all-reduce of a flat gradient buffer.
+
+    Buckets are contiguous slices, reduced in the order the backward pass
+    finishes them.  Works on any torch.distributed backend (RCCL on GPUs; gloo
+    in the CPU tests)."""
+
+    def __init__(self, flat_grad, ranges, group=None):
+        self.flat, self.ranges, self.group = flat_grad, list(ranges), group
+        covered = sorted(self.ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel()
+        for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
+            assert a1 == b0, 'gradient buckets must tile the flat buffer'
+        self._pending = []
+
+    def reduce_bucket(self, i):
+        import torch.distributed as dist
+        s, e = self.ranges[i]
+        self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+
+class StyleTrainer:
+    def __init__(self, batch, height, width, device, vgg_weights, vgg_mean, style_weight, content_weight, tv_weight,
+                 dtype=torch.float32, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, params=None, seed=1,
+                 world_size=1, group=None, use_graph=True):
+        self.n, self.h, self.w, self.device, self.dtype = batch, height, width, device, dtype
+        self.sw, self.cw, self.tvw = style_weight, content_weight, tv_weight
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.world, self.group, self.use_graph = world_size, group, use_graph
+        self.net = StylizerNet(batch, height, width, device, dtype, params=params, seed=seed, training=True)
+        self.vgg = VggFeatures(vgg_weights, vgg_mean, device, dtype)
+        self.rep_content = self.vgg.replica(batch, height, width, keep_for_backward=False)
+        self.rep_loss = self.vgg.replica(batch, height, width, keep_for_backward=True)
+        self.batch_in = torch.empty((batch, height, width, 3), dtype=torch.float32, device=device)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=device)  # total, style, content, tv
+        self.m = torch.zeros_like(self.net.flat)
+        self.v = torch.zeros_like(self.net.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.style_targets = None
+        self.buckets = None
+        if world_size > 1:
+            self.buckets = GradBuckets(self.net.flat_grad, [self.net.param_range(hi, lo) for hi, lo in BWD_SEGMENTS],
+                                       group)
+        self._graphs = None
+
+    # ------------------------------------------------------------- targets
+    def set_style_image(self, style_f32):
+        """Gram targets of a style image of any size [1,H,W,3] (full_graph_stylizer_network.py:185)."""
+        _, h, w, _ = style_f32.shape
+        rep = self.vgg.replica(1, h, w, keep_for_backward=False)
+        grams, _ = rep.forward(style_f32.to(self.device, torch.float32).contiguous())
+        self.style_targets = [g.clone() for g in grams]
+        torch.cuda.synchronize()
+        return self.style_targets
+
+    # --------------------------------------------------------------- pieces
+    def _front(self):
+        self.losses.zero_()
+        self.net.flat_grad.zero_()
+        _, content_target = self.rep_content.forward(self.batch_in)
+        out = self.net.forward(self.batch_in)
+        d_out = self.rep_loss.loss_and_grad(out, self.style_targets, content_target,
+                                            self.sw, self.cw, self.tvw, self.losses)
+        return d_out
+
+    def _update(self):
+        ops.adam_tf1(self.net.flat, self.net.flat_grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
+                     grad_scale=1.0 / self.world, step_dev=self.step_dev)
+        self.net.repack()
+
+    def _segments(self):
+        """The step as a list of callables; an all-reduce bucket becomes ready after each but the last."""
+        segs = []
+        for si, (hi, lo) in enumerate(BWD_SEGMENTS):
+            if si == 0:
+                segs.append(lambda hi=hi, lo=lo: self.net.backward(self._front(), hi, lo))
+            else:
+                segs.append(lambda hi=hi, lo=lo: self.net.backward(None, hi, lo))
+        segs.append(self._update)
+        return segs
+
+    def _run_eager(self):
+        segs = self._segments()
+        for i, seg in enumerate(segs):
+            seg()
+            if self.buckets is not None and i < len(BWD_SEGMENTS):
+                self.buckets.reduce_bucket(i)
+            if self.buckets is not None and i == len(BWD_SEGMENTS) - 1:
+                self.buckets.wait()
+
+    def _capture(self):
+        # warm-up on a side stream (graph capture needs every lazy initialisation done)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._run_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        segs = self._segments()
+        if self.buckets is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for seg in segs:
+                    seg()
+            self._graphs = [g]
+        else:
+            self._graphs = []
+            pool = None
+            for seg in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    seg()
+                pool = g.pool()
+                self._graphs.append(g)
+
+    # ----------------------------------------------------------------- step
+    def step(self, batch_f32=None):
+        """One optimisation step on `batch_f32` (fp32 [n,h,w,3] in [0,1]); None re-uses the staged batch."""
+        assert self.style_targets is not None, 'call set_style_image first'
+        if batch_f32 is not None:
+            self.batch_in.copy_(batch_f32, non_blocking=True)
+        if not self.use_graph:
+            self._run_eager()
+            return
+        if self._graphs is None:
+            state = (self.net.flat.clone(), self.m.clone(), self.v.clone(), self.step_dev.clone())
+            self._capture()
+            # the warm-up pass updated the weights once: restore so that capture is not a step
+            self.net.flat.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2]); self.step_dev.copy_(state[3])
+            self.net.repack()
+        if self.buckets is None:
+            self._graphs[0].replay()
+        else:
+            for i, g in enumerate(self._graphs):
+                g.replay()
+                if i < len(BWD_SEGMENTS):
+                    self.buckets.reduce_bucket(i)
+                if i == len(BWD_SEGMENTS) - 1:
+                    self.buckets.wait()
+
+    def read_losses(self):
+        """[total, style, content, tv] of the last step (synchronises)."""
+        l = self.losses.cpu().numpy().astype(np.float64)
+        l[0] = l[1] + l[2] + l[3]
+        return l
+
+    def stylize(self, x_f32):
+        """Forward of the current weights on a batch of the training shape."""
+        return self.net.forward(x_f32.to(self.device, torch.float32).contiguous()).clone()
+
+
+class GatysOptimizer:
+    """Adam(0.02, beta1 .99, eps 1e-1) on the image itself (full_graph_stylizer_network.py:278-279)."""
+
+    def __init__(self, content_f32, device, vgg_weights, vgg_mean, style_weight, content_weight, tv_weight,
+                 dtype=torch.float32, lr=0.02, beta1=0.99, beta2=0.999, eps=1e-1, use_graph=True):
+        _, h, w, _ = content_f32.shape
+        self.device, self.dtype = device, dtype
+        self.sw, self.cw, self.tvw = style_weight, content_weight, tv_weight
+        self.lr, self.b1, self.b2, self.eps, self.use_graph = lr, beta1, beta2, eps, use_graph
+        self.vgg = VggFeatures(vgg_weights, vgg_mean, device, dtype)
+        self.rep = self.vgg.replica(1, h, w, keep_for_backward=True)
+        self.image = content_f32.to(device, torch.float32).contiguous().clone()   # tf.Variable(content_image), :257
+        content_rep = self.vgg.replica(1, h, w, keep_for_backward=False)
+        _, c = content_rep.forward(self.image)
+        self.content_target = c.clone()
+        self.style_targets = None
+        self.grad32 = torch.empty_like(self.image)
+        self.m = torch.zeros_like(self.image)
+        self.v = torch.zeros_like(self.image)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=device)
+        self._graph = None
+
+    def set_style_image(self, style_f32):
+        _, h, w, _ = style_f32.shape
+        rep = self.vgg.replica(1, h, w, keep_for_backward=False)
+        grams, _ = rep.forward(style_f32.to(self.device, torch.float32).contiguous())
+        self.style_targets = [g.clone() for g in grams]
+        torch.cuda.synchronize()
+
+    def _run(self):
+        self.losses.zero_()
+        d = self.rep.loss_and_grad(self.image, self.style_targets, self.content_target, self.sw, self.cw, self.tvw,
+                                   self.losses)
+        if self.dtype == torch.float32:
+            g = d
+        else:
+            g = ops.cast(d, torch.float32, out=self.grad32)
+        ops.adam_tf1(self.image, g, self.m, self.v, self.lr, self.b1, self.b2, self.eps, step_dev=self.step_dev)
+        # the reference's clip (:328-329) only builds an un-run assign op: the image is NOT clipped
+
+    def step(self):
+        assert self.style_targets is not None
+        if not self.use_graph:
+            self._run()
+            return
+        if self._graph is None:
+            state = (self.image.clone(), self.m.clone(), self.v.clone(), self.step_dev.clone())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._run()
+            self.image.copy_(state[0]); self.m.copy_(state[1]); self.v.copy_(state[2]); self.step_dev.copy_(state[3])
+        self._graph.replay()
+
+    def read_losses(self):
+        l = self.losses.cpu().numpy().astype(np.float64)
+        l[0] = l[1] + l[2] + l[3]
+        return l
