@@ -183,6 +183,9 @@ int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count,
 /* ---- small utilities --------------------------------------------------- */
 /* dtype conversion between fp32 and `dtype`; to_f32 != 0 converts dtype -> fp32 */
 int stmi_cast(const void* src, void* dst, long count, int dtype, int to_f32, void* stream);
+/* tf.nn.relu / tf.nn.sigmoid applied on their own (model_utilities.py:240-241 when a block
+ * has no instance norm to fuse them into); y may alias x. */
+int stmi_activation(const void* x, void* y, long count, int act, int dtype, void* stream);
 /* tf.clip_by_value(x, lo, hi) in place, fp32           (model_utilities.py:365-366) */
 int stmi_clip(float* x, long count, float lo, float hi, void* stream);
 

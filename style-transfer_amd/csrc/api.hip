@@ -42,6 +42,7 @@ int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* 
 int scale_shift_impl(const float*, const float*, void*, float, long, int, int, hipStream_t);
 int cast_impl(const void*, void*, long, int, int, hipStream_t);
 int clip_impl(float*, long, float, float, hipStream_t);
+int activation_impl(const void*, void*, long, int, int, hipStream_t);
 int pool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
 int pool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int mse_impl(const void*, const void*, void*, float*, float, float, long, int, hipStream_t);
@@ -264,6 +265,13 @@ int stmi_cast(const void* src, void* dst, long count, int dtype, int to_f32, voi
     STMI_REQUIRE(src && dst && count >= 0, "cast: bad arguments");
     if (count == 0) return STMI_OK;
     return cast_impl(src, dst, count, dtype, to_f32, S(stream));
+}
+
+int stmi_activation(const void* x, void* y, long count, int act, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && y && count >= 0 && act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "activation: bad arguments");
+    if (count == 0) return STMI_OK;
+    return activation_impl(x, y, count, act, dtype, S(stream));
 }
 
 int stmi_clip(float* x, long count, float lo, float hi, void* stream) {

@@ -50,6 +50,22 @@ int cast_impl(const void* src, void* dst, long count, int dtype, int to_f32_flag
     return STMI_OK;
 }
 
+template <typename T>
+__global__ void activation_kernel(const T* __restrict__ x, T* __restrict__ y, long count, int act) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float v = to_f32<T>(x[i]);
+        y[i] = from_f32<T>(act == STMI_ACT_RELU ? fmaxf(v, 0.f) : act == STMI_ACT_SIGMOID ? 1.f / (1.f + __expf(-v)) : v);
+    }
+}
+
+int activation_impl(const void* x, void* y, long count, int act, int dtype, hipStream_t s) {
+    const dim3 grid(flat_blocks(count)), block(256);
+    if (dtype == STMI_BF16) hipLaunchKernelGGL(activation_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, count, act);
+    else hipLaunchKernelGGL(activation_kernel<float>, grid, block, 0, s, (const float*)x, (float*)y, count, act);
+    STMI_LAUNCH_CHECK("activation_kernel");
+    return STMI_OK;
+}
+
 __global__ void clip_kernel(float* x, long count, float lo, float hi) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
         x[i] = fminf(fmaxf(x[i], lo), hi);

@@ -1,0 +1,368 @@
+"""Drop-in for the reference's src/full_graph_stylizer_network.py.
+
+Command line (same argv forms as the reference, full_graph_stylizer_network.py:407-433):
+    full_graph_stylizer_network.py SRC DST                 newest STYLE_NET model
+    full_graph_stylizer_network.py MODEL SRC DST           models/MODEL
+    full_graph_stylizer_network.py MODEL BASE_DIR SRC DST  BASE_DIR/MODEL
+    anything else                                          train_style_network('heiro_4')
+
+StyleNetService, run_on_image, train_style_network, normal_style_transfer and
+build_style_network keep their names, arguments and defaults; the work is done by the
+HIP executors in ``stmi`` instead of a TensorFlow session.  Trained weights are stored
+as ``saved_<model>-0.npz`` (48 arrays keyed like the reference's checkpoint variables,
+``style_network/Variable``, ``style_network/Variable_1`` ...) next to a ``checkpoint``
+file naming the newest one.
+"""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if os.path.join(HERE, '..') not in sys.path:
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, '..')))
+
+import constants
+import model_utilities
+from image_utilities import load_image, CocoDatasetManager, save_image, PreprocessedCocoDatasetManager  # noqa: F401
+from model_utilities import LayerConfig, StyleTransfer, nn
+from vgg import *  # noqa: F401,F403  (the reference re-exports the vgg names the same way)
+import vgg as _vgg
+
+LEARNING_RATE = 1e-3
+EPOCHS = 80
+BATCH_SIZE = 4
+TOTAL_IMAGES = 1000
+
+STYLE_IMAGE_1 = os.path.join(constants.STYLES_DIR, 'starry_night_small.jpg')
+STYLE_IMAGE_1_LARGE = os.path.join(constants.STYLES_DIR, 'starry_night.jpg')
+STYLE_IMAGE_2_LARGE = os.path.join(constants.STYLES_DIR, 'honeycomb_large.jpg')
+STYLE_IMAGE_2_SQUEEZE = os.path.join(constants.STYLES_DIR, 'honeycomb_squeeze.jpg')
+
+CONTENT_IMAGE_1 = os.path.join(constants.CONTENT_DIR, 'antelope_small.jpg')
+CONTENT_IMAGE_1_2 = os.path.join(constants.CONTENT_DIR, 'antelope_256.jpg')
+CONTENT_IMAGE_2 = os.path.join(constants.CONTENT_DIR, 'sparrow_small.jpg')
+CONTENT_IMAGE_2_LARGE = os.path.join(constants.CONTENT_DIR, 'sparrow.jpg')
+CONTENT_IMAGE_3 = os.path.join(constants.CONTENT_DIR, 'museum.jpg')
+
+model_prefix = 'STYLE_NET'
+
+TRAIN_IMG_DIMS = [None, 256, 256, 3]
+
+
+def _compute_dtype():
+    return torch.bfloat16 if os.environ.get('STMI_DTYPE', 'f32') == 'bf16' else torch.float32
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('no MI355X visible: the stylizer runs on HIP kernels only, there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+# --------------------------------------------------------------------------
+# network definition (reference :42-82)
+# --------------------------------------------------------------------------
+def build_style_network(network_input):
+    conv_layer_configs = [LayerConfig(32, 9, 1), LayerConfig(64, 3, 2), LayerConfig(128, 3, 2)]
+    residual_block_configs = [LayerConfig(128, 3, 1) for _ in range(5)]
+    deconv_layer_configs = [LayerConfig(64, 3, 2), LayerConfig(32, 3, 2)]
+    last_layer = LayerConfig(3, 9, 1, activation=nn.sigmoid)
+
+    model_builder = model_utilities.NNGraphModelBuilder
+    layer = network_input
+    for x in conv_layer_configs:
+        layer = model_builder.conv_block(layer, x)
+    for x in residual_block_configs:
+        layer = model_builder.residual_block(layer, x)
+    for x in deconv_layer_configs:
+        layer = model_builder.deconv_block(layer, x)
+    layer = model_builder.conv_block(layer, last_layer)
+
+    layer_configs = {
+        'conv_layers': [repr(x) for x in conv_layer_configs],
+        'residual_layers': [repr(x) for x in residual_block_configs],
+        'deconv_layers': [repr(x) for x in deconv_layer_configs],
+    }
+    return layer, layer_configs
+
+
+# --------------------------------------------------------------------------
+# weight files
+# --------------------------------------------------------------------------
+def _var_key(i):
+    return 'style_network/Variable' if i == 0 else 'style_network/Variable_%d' % i
+
+
+def save_checkpoint(params, model_dir, model_name, global_step=0):
+    """48 arrays in creation order -> <model_dir>/saved_<model_name>-<step>.npz + 'checkpoint'."""
+    base = 'saved_%s-%d' % (model_name, global_step)
+    np.savez(os.path.join(model_dir, base + '.npz'), **{_var_key(i): np.asarray(p) for i, p in enumerate(params)})
+    with open(os.path.join(model_dir, 'checkpoint'), 'w') as fl:
+        fl.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+    return os.path.join(model_dir, base + '.npz')
+
+
+def latest_checkpoint(model_dir):
+    """Path of the newest weight file in model_dir, or None (tf.train.latest_checkpoint's role)."""
+    marker = os.path.join(model_dir, 'checkpoint')
+    if os.path.exists(marker):
+        with open(marker) as fl:
+            for line in fl:
+                if line.startswith('model_checkpoint_path:'):
+                    base = line.split(':', 1)[1].strip().strip('"')
+                    path = os.path.join(model_dir, base + '.npz')
+                    if os.path.exists(path):
+                        return path
+    found = sorted(x for x in os.listdir(model_dir) if x.endswith('.npz')) if os.path.isdir(model_dir) else []
+    return os.path.join(model_dir, found[-1]) if found else None
+
+
+def load_checkpoint(path):
+    with np.load(path) as z:
+        return [z[_var_key(i)] for i in range(len(z.files))]
+
+
+def _load_vgg_for_training():
+    """The VGG weights, and the preprocessing mean the reference's training graph ends up
+    with: its vgg_preprocess_input calls are evaluated before the builder assigns the
+    module global, so the graph is built with the mean still [0,0,0]
+    (full_graph_stylizer_network.py:107-108 with vgg.py:9, :72-74)."""
+    mean_at_graph_build = np.asarray(_vgg.vgg_preprocessing_mean, dtype=np.float32).copy()
+    path = _vgg.VGG_PATH_REPLICATE if os.path.exists(_vgg.VGG_PATH_REPLICATE) else _vgg.VGG_PATH
+    weights, mean_pixel = _vgg.load_vgg_mat(path)
+    _vgg.vgg_preprocessing_mean = mean_pixel
+    return weights, mean_at_graph_build
+
+
+# --------------------------------------------------------------------------
+# training (reference :85-232)
+# --------------------------------------------------------------------------
+def train_style_network(style_type, test_content_image_path=CONTENT_IMAGE_1_2, dataset_manager=None,
+                        epochs=None, log=print):
+    from stmi.stylizer import StylizerNet
+    from stmi.trainer import StyleTrainer
+    style_config = StyleTransfer.STYLE_CONFIG_DICT[style_type]
+    style_image = load_image(style_config.style_path)
+    test_content_image = load_image(test_content_image_path)
+    device, dtype = _device(), _compute_dtype()
+    epochs = EPOCHS if epochs is None else epochs
+
+    log('Building networks...')
+    vgg_weights, vgg_mean = _load_vgg_for_training()
+    trainer = StyleTrainer(BATCH_SIZE, TRAIN_IMG_DIMS[1], TRAIN_IMG_DIMS[2], device, vgg_weights, vgg_mean,
+                           style_config.style_weight, style_config.content_weight,
+                           style_config.total_variation_weight, dtype=dtype, lr=LEARNING_RATE)
+    # the last batch of an epoch is ragged (1001 images, batch 4): it gets its own executor
+    tail_trainers = {}
+    log('Done building networks.')
+
+    log('Loading images...')
+    if dataset_manager is None:
+        dataset_manager = PreprocessedCocoDatasetManager(target_dim=(256, 256), num_images=TOTAL_IMAGES)
+    log('Done loading images.')
+
+    model_name = time.strftime(model_prefix + '_%Y-%m-%d-%H-%M') + '_' + style_type
+    target_dir = os.path.join(constants.MODELS_DIR, model_name)
+    os.mkdir(target_dir)
+    _, style_network_configs = _layer_config_strings()
+    style_network_configs['style_config'] = repr(style_config)
+    style_network_configs['style_layers'] = StyleTransfer.VGG_STYLE_TARGET_LAYER_NAMES
+    style_network_configs['content_layers'] = StyleTransfer.VGG_CONTENT_TARGET_LAYER_NAMES
+    style_network_configs['batch_size'] = BATCH_SIZE
+    style_network_configs['data_size'] = TOTAL_IMAGES
+    style_network_configs['epochs'] = epochs
+    style_network_configs['LR'] = LEARNING_RATE
+    style_network_configs['config_name'] = style_type
+    with open(os.path.join(target_dir, 'config.json'), 'w+') as fl:
+        json.dump(style_network_configs, fl, indent=4)
+    loss_log = open(os.path.join(target_dir, 'losses.jsonl'), 'w')
+
+    trainer.set_style_image(torch.from_numpy(np.ascontiguousarray(style_image)))
+    sampler = StylizerNet(1, test_content_image.shape[1], test_content_image.shape[2], device, dtype)
+    train_start_time = time.time()
+    for epoch in range(epochs):
+        dataset_manager.shuffle_loaded_images()
+        images = dataset_manager.get_images()
+        log('Epoch ' + str(epoch + 1) + ' of ' + str(epochs))
+        num_training_steps = int(len(images) / BATCH_SIZE) + 1
+        for step in range(num_training_steps):
+            start = min(len(images), step * BATCH_SIZE)
+            end = min(len(images), (step + 1) * BATCH_SIZE)
+            if start == end:
+                continue
+            batch = torch.from_numpy(np.ascontiguousarray(np.array(images[start:end], dtype=np.float32)))
+            if end - start == BATCH_SIZE:
+                active = trainer
+            else:
+                active = _tail_trainer(tail_trainers, trainer, end - start, vgg_weights, vgg_mean, style_config, dtype)
+            active.step(batch.to(device))
+            if active is not trainer:
+                _sync_back(active, trainer)
+            if step % max(int(num_training_steps / 10), 1) == 0:
+                total, style_l, content_l, tv_l = active.read_losses()
+                loss_log.write(json.dumps({'step': epoch * num_training_steps + step, 'total': total, 'style': style_l,
+                                           'content': content_l, 'tv': tv_l}) + '\n')
+                loss_log.flush()
+        sampler.load_params(trainer.net.export_params())
+        sampler.repack()
+        sampled_image = sampler.forward(torch.from_numpy(np.ascontiguousarray(test_content_image)).to(device))
+        save_image(sampled_image.cpu().numpy(), os.path.join(target_dir, str(epoch) + '_style_transfer_sample.jpg'))
+        elapsed = time.time() - train_start_time
+        eta = (elapsed / max(1, epoch + 1)) * (epochs - (epoch + 1))
+        log('elapsed: ' + str(elapsed / 60.)[:6] + ' min | remaining training time: ' + str(eta / 60.)[:6] + ' min')
+    log('Training concluded. Saving model...')
+    save_checkpoint(trainer.net.export_params(), target_dir, model_name, global_step=0)
+    loss_log.close()
+    log('Model saved.')
+    return model_name
+
+
+def _layer_config_strings():
+    convs = [LayerConfig(32, 9, 1), LayerConfig(64, 3, 2), LayerConfig(128, 3, 2)]
+    res = [LayerConfig(128, 3, 1) for _ in range(5)]
+    dec = [LayerConfig(64, 3, 2), LayerConfig(32, 3, 2)]
+    return None, {'conv_layers': [repr(x) for x in convs], 'residual_layers': [repr(x) for x in res],
+                  'deconv_layers': [repr(x) for x in dec]}
+
+
+def _tail_trainer(cache, main, n, vgg_weights, vgg_mean, style_config, dtype):
+    """Executor for a ragged batch of n images sharing the main trainer's state."""
+    from stmi.trainer import StyleTrainer
+    if n not in cache:
+        t = StyleTrainer(n, main.h, main.w, main.device, vgg_weights, vgg_mean, style_config.style_weight,
+                         style_config.content_weight, style_config.total_variation_weight, dtype=dtype, lr=main.lr,
+                         use_graph=False)
+        t.style_targets = main.style_targets
+        cache[n] = t
+    t = cache[n]
+    t.net.flat.copy_(main.net.flat); t.m.copy_(main.m); t.v.copy_(main.v); t.step_dev.copy_(main.step_dev)
+    t.net.repack()
+    return t
+
+
+def _sync_back(tail, main):
+    main.net.flat.copy_(tail.net.flat); main.m.copy_(tail.m); main.v.copy_(tail.v); main.step_dev.copy_(tail.step_dev)
+    main.net.repack()
+
+
+# --------------------------------------------------------------------------
+# Gatys optimisation (reference :235-346)
+# --------------------------------------------------------------------------
+def normal_style_transfer(style_type, epochs=None, steps_per_epoch=100, log=print):
+    from stmi.trainer import GatysOptimizer
+    style_config = StyleTransfer.STYLE_CONFIG_DICT[style_type]
+    style_image_1 = load_image(style_config.style_path)
+    content_image_1 = load_image(CONTENT_IMAGE_1)
+    device, dtype = _device(), _compute_dtype()
+    epochs = EPOCHS if epochs is None else epochs
+    vgg_weights, vgg_mean = _load_vgg_for_training()
+    opt = GatysOptimizer(torch.from_numpy(np.ascontiguousarray(content_image_1)), device, vgg_weights, vgg_mean,
+                         style_config.style_weight, style_config.content_weight, style_config.total_variation_weight,
+                         dtype=dtype)
+    opt.set_style_image(torch.from_numpy(np.ascontiguousarray(style_image_1)))
+    train_start_time = time.time()
+    for epoch in range(epochs):
+        log('Epoch ' + str(epoch + 1) + ' of ' + str(epochs))
+        for _ in range(steps_per_epoch):
+            opt.step()
+        save_image(opt.image.cpu().numpy(),
+                   os.path.join(constants.STYLIZED_IMAGES_DIR, str(epoch) + '_style_transfer_sample_1.jpg'))
+        elapsed = time.time() - train_start_time
+        eta = (elapsed / max(1, epoch + 1)) * (epochs - (epoch + 1))
+        log('elapsed: ' + str(elapsed / 60.)[:6] + ' min | remaining training time: ' + str(eta / 60.)[:6] + ' min')
+    return opt.image.cpu().numpy()
+
+
+# --------------------------------------------------------------------------
+# inference service (reference :349-405)
+# --------------------------------------------------------------------------
+class StyleNetService(threading.Thread):
+    """Thread-backed model holder.  start() loads the weights and flips `loaded`; run_on_image
+    may then be called from any thread (calls are serialised per service: one GPU stream's
+    worth of work each; executors are cached per image size)."""
+
+    def __init__(self, model_name, model_dir=constants.MODELS_DIR):
+        super().__init__()
+        self.model_name = model_name
+        self.model_dir = model_dir
+        self.loaded = False
+        self._lock = threading.Lock()
+        self._nets = {}
+        self._params = None
+
+    def run(self):
+        print('StyleNetService starting...')
+        model_dir = os.path.join(self.model_dir, self.model_name)
+        if not os.path.isdir(model_dir) and os.path.isdir(self.model_name):
+            model_dir = self.model_name   # the 4-argument CLI form hands over an already joined path
+        path = latest_checkpoint(model_dir)
+        if path is None:
+            raise FileNotFoundError('no saved_*.npz weight file in ' + model_dir)
+        self._params = load_checkpoint(path)
+        self._device = _device()
+        print('StyleNetService running.')
+        self.loaded = True
+
+    def run_on_image(self, input_image):
+        from stmi.stylizer import StylizerNet
+        x = np.ascontiguousarray(np.asarray(input_image, dtype=np.float32))
+        n, h, w, _ = x.shape
+        with self._lock:
+            with torch.cuda.device(self._device):
+                net = self._nets.get((n, h, w))
+                if net is None:
+                    net = StylizerNet(n, h, w, self._device, _compute_dtype(), params=self._params)
+                    self._nets = {(n, h, w): net}      # keep one shape resident; 1080p buffers are large
+                out = net.forward(torch.from_numpy(x).to(self._device))
+                return out.cpu().numpy()
+
+    def close(self):
+        self._nets = {}
+
+    def wait_for_ready(self, increment=.1):
+        while not self.loaded:
+            time.sleep(increment)
+
+
+def run_on_image(source_image_path, destination_path, model_path=None, model_dir=constants.MODELS_DIR):
+    target_image = load_image(source_image_path)
+    real_model_path = model_path
+    if real_model_path is None:
+        real_model_path = model_utilities.get_most_recent_model_name(model_dir, model_prefix)
+    service = StyleNetService(real_model_path, model_dir)
+    service.start()
+    service.wait_for_ready()
+    output_image = service.run_on_image(target_image)
+    save_image(output_image, destination_path)
+    service.close()
+
+
+def main(argv):
+    if len(argv) == 3:
+        src, dest = argv[1], argv[2]
+        if os.path.exists(src):
+            run_on_image(src, dest)
+    elif len(argv) == 4:
+        model, src, dest = argv[1], argv[2], argv[3]
+        model_dir = os.path.join(constants.MODELS_DIR, model)
+        if os.path.exists(src) and os.path.exists(model_dir) and os.path.isdir(model_dir):
+            run_on_image(src, dest, model_path=model)
+    elif len(argv) == 5:
+        model, model_base_dir, src, dest = argv[1], argv[2], argv[3], argv[4]
+        model_dir = os.path.join(model_base_dir, model)
+        print('--' + model_dir)
+        if os.path.exists(src) and os.path.exists(model_dir) and os.path.isdir(model_dir):
+            # the reference passes the JOINED path as the model name here; os.path.join then
+            # ignores model_base_dir only when that path is absolute.  Kept as is.
+            run_on_image(src, dest, model_path=model_dir, model_dir=model_base_dir)
+    else:
+        train_style_network('heiro_4')
+
+
+if __name__ == '__main__':
+    main(sys.argv)

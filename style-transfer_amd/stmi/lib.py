@@ -46,6 +46,7 @@ SIGNATURES = {
     'stmi_tv_loss_fwd_bwd': (_c_int, [_vp] * 3 + [_c_float] + [_c_int] * 5 + [_vp]),
     'stmi_adam_tf1': (_c_int, [_vp] * 4 + [_c_long] + [_c_float] * 5 + [_vp, _c_int, _vp]),
     'stmi_cast': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
+    'stmi_activation': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_clip': (_c_int, [_vp, _c_long, _c_float, _c_float, _vp]),
 }
 

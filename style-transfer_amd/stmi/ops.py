@@ -348,6 +348,13 @@ def cast(src, dtype, out=None):
     return dst
 
 
+def activation(x, act, out=None):
+    _chk(x, 'x')
+    y = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
+    _lib.call('stmi_activation', x.data_ptr(), y.data_ptr(), x.numel(), act, _dt(x), _stream())
+    return y
+
+
 def clip_(x, lo, hi):
     _chk(x, 'x', torch.float32)
     _lib.call('stmi_clip', x.data_ptr(), x.numel(), float(lo), float(hi), _stream())
