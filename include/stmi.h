@@ -49,8 +49,9 @@ const char* stmi_last_error(void);
 int stmi_device_arch(char* buf, int buflen);
 
 /* Profiling aid: the name a profiler shows for the kernel instantiation that a stride-1
- * convolution (forward or backward-data) writing `out_channels` x `out_pixels` launches. */
-int stmi_conv_kernel_name(int out_channels, long out_pixels, int dtype, char* buf, int buflen);
+ * convolution (forward or backward-data) writing `out_channels` x `out_pixels` and reducing
+ * over `k_channels` channels per tap launches. */
+int stmi_conv_kernel_name(int out_channels, long out_pixels, int k_channels, int dtype, char* buf, int buflen);
 
 /* ---- weight packing ---------------------------------------------------- */
 /* Weights live as fp32 HWIO [kh,kw,ci,co] (the layout of the reference's
@@ -110,18 +111,18 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
  * followed by the block's activation (model_utilities.py:240-241) and, for the
  * second conv of a residual block, the skip add (model_utilities.py:278).
  *
- * stats  : per-(n,c) shifted partial sums -> ws (stmi_instance_norm_ws_floats floats)
- * apply  : y = act(scale*xhat + shift) [+ residual]; optional fp32 copy y_f32;
- *          writes mean/rstd pairs to stats_out [n,c,2] (fp32) when not NULL.
+ * stats  : stats[n,c,2] (fp32) = (mean, 1/sqrt(var+eps)) per sample and channel; ws is
+ *          scratch of stmi_instance_norm_ws_floats floats (per-block partial sums).
+ * apply  : y = act(scale*xhat + shift) [+ residual]; optional fp32 copy y_f32.
  * bwd    : from dy (gradient w.r.t. y) to dx, and ADDS the parameter gradients
  *          into dscale[c], dshift[c] (fp32).  The activation gradient is
  *          recomputed from x, so y is not needed. */
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
-int stmi_instance_norm_nhwc_stats(const void* x, float* ws, int n, int h, int w, int c,
-                                  int dtype, void* stream);
-int stmi_instance_norm_nhwc_apply(const void* x, const float* ws, const float* scale, const float* shift,
-                                  const void* residual, void* y, float* y_f32, float* stats_out,
-                                  float eps, int act, int n, int h, int w, int c,
+int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float eps,
+                                  int n, int h, int w, int c, int dtype, void* stream);
+int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float* scale, const float* shift,
+                                  const void* residual, void* y, float* y_f32,
+                                  int act, int n, int h, int w, int c,
                                   int dtype, void* stream);
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats,
                                 const float* scale, const float* shift,

@@ -21,7 +21,7 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 // implemented in the kernel translation units
-void conv_kernel_name(int rows, long pixels, int dtype, char* buf, int buflen);
+void conv_kernel_name(int rows, long pixels, int kchannels, int dtype, char* buf, int buflen);
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s);
@@ -33,10 +33,10 @@ int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
 long in_ws_floats(int n, int h, int w, int c);
-int in_stats_impl(const void* x, float* ws, int n, int h, int w, int c, int dtype, hipStream_t s);
-int in_apply_impl(const void* x, const float* ws, const float* scale, const float* shift, const void* residual,
-                  void* y, float* y_f32, float* stats_out, float eps, int act, int n, int h, int w, int c, int dtype,
+int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
+int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
+                  void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
                 float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
 int scale_shift_impl(const float*, const float*, void*, float, long, int, int, hipStream_t);
@@ -88,10 +88,10 @@ int stmi_device_arch(char* buf, int buflen) {
     return STMI_OK;
 }
 
-int stmi_conv_kernel_name(int out_channels, long out_pixels, int dtype, char* buf, int buflen) {
+int stmi_conv_kernel_name(int out_channels, long out_pixels, int k_channels, int dtype, char* buf, int buflen) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(buf && buflen > 0 && out_channels > 0 && out_pixels > 0, "conv_kernel_name: bad arguments");
-    conv_kernel_name(out_channels, out_pixels, dtype, buf, buflen);
+    STMI_REQUIRE(buf && buflen > 0 && out_channels > 0 && out_pixels > 0 && k_channels > 0, "conv_kernel_name: bad arguments");
+    conv_kernel_name(out_channels, out_pixels, k_channels, dtype, buf, buflen);
     return STMI_OK;
 }
 
@@ -156,21 +156,22 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, i
 
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c) { return in_ws_floats(n, h, w, c); }
 
-int stmi_instance_norm_nhwc_stats(const void* x, float* ws, int n, int h, int w, int c, int dtype, void* stream) {
+int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c,
+                                  int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(x && ws && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_stats: bad arguments");
+    STMI_REQUIRE(x && ws && stats && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_stats: bad arguments");
     if (n == 0) return STMI_OK;
-    return in_stats_impl(x, ws, n, h, w, c, dtype, S(stream));
+    return in_stats_impl(x, ws, stats, eps, n, h, w, c, dtype, S(stream));
 }
 
-int stmi_instance_norm_nhwc_apply(const void* x, const float* ws, const float* scale, const float* shift,
-                                  const void* residual, void* y, float* y_f32, float* stats_out, float eps, int act,
+int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float* scale, const float* shift,
+                                  const void* residual, void* y, float* y_f32, int act,
                                   int n, int h, int w, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(x && ws && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_apply: bad arguments");
+    STMI_REQUIRE(x && stats && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_apply: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_apply: bad activation %d", act);
     if (n == 0) return STMI_OK;
-    return in_apply_impl(x, ws, scale, shift, residual, y, y_f32, stats_out, eps, act, n, h, w, c, dtype, S(stream));
+    return in_apply_impl(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype, S(stream));
 }
 
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats, const float* scale,

@@ -17,28 +17,9 @@
 // Accumulators are laid out co-major (row = 4*(lane>>4)+reg), so a lane owns 4
 // consecutive channels of one pixel and the epilogue stores 8 or 16 bytes per
 // lane into NHWC.
-#include "common.hpp"
+#include "conv_gemm.hpp"
 
 namespace stmi {
-
-struct ConvGemmParams {
-    const void* in;
-    const void* wp;
-    void* out;
-    void* out_pre;
-    const float* bias;
-    const void* mask;
-    const void* addend;
-    int N, Hi, Wi, Ci;  // gathered tensor
-    int Ho, Wo, Co;     // written tensor
-    int Hs, Ws, oy0, ox0, oys, oxs;  // output sub-grid
-    int in_stride;      // input base position = sub-grid index * in_stride
-    int ntaps, klen, kpad, cdiv, co_pad;
-    long w_batch_stride;  // != 0: one weight set per sample (Gram backward)
-    float alpha;
-    int relu;
-    Tap taps[kMaxTaps];
-};
 
 // chunk swizzle of a 64-byte LDS row: conflict-free ds_read_b128 for the
 // 16-row x 4-chunk fragment pattern (rows r and r+4 land on distinct slots
@@ -190,68 +171,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         }
     }
 
-    // epilogue: lane owns channels co..co+3 of pixel column r16 in every tile
-    T* out = (T*)p.out;
-    T* out_pre = (T*)p.out_pre;
-    const T* mask = (const T*)p.mask;
-    const T* addend = (const T*)p.addend;
-    const bool vec_ok = (p.Co & 3) == 0;
-#pragma unroll
-    for (int tp = 0; tp < TP; tp++) {
-        const long m = pix0 + (wpx * TP + tp) * 16 + r16;
-        if (m >= Mz) continue;
-        const long mm = m + zoff;
-        const int n = (int)(mm / HWs);
-        const int rem = (int)(mm - (long)n * HWs);
-        const int i = rem / p.Ws, j = rem - i * p.Ws;
-        const long off = (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
-#pragma unroll
-        for (int tc = 0; tc < TC; tc++) {
-            const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
-            if (co >= p.Co) continue;
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = acc[tc][tp][u];
-            if (p.bias) {
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (co + u < p.Co) v[u] += p.bias[co + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] *= p.alpha;
-            if (vec_ok) {
-                if (mask) {
-                    float mk[4];
-                    load_vec<T, 4>(mask + off + co, mk);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
-                }
-                if (addend) {
-                    float ad[4];
-                    load_vec<T, 4>(addend + off + co, ad);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] += ad[u];
-                }
-                if (out_pre) store_vec<T, 4>(out_pre + off + co, v);
-                if (p.relu) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = fmaxf(v[u], 0.f);
-                }
-                store_vec<T, 4>(out + off + co, v);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (co + u >= p.Co) continue;
-                    float x = v[u];
-                    if (mask) x = to_f32<T>(mask[off + co + u]) > 0.f ? x : 0.f;
-                    if (addend) x += to_f32<T>(addend[off + co + u]);
-                    if (out_pre) out_pre[off + co + u] = from_f32<T>(x);
-                    if (p.relu) x = fmaxf(x, 0.f);
-                    out[off + co + u] = from_f32<T>(x);
-                }
-            }
-        }
-    }
+    conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wc, wpx, g, r16, Mz, zoff, HWs);
 }
 
 // ---------------------------------------------------------------------------
@@ -295,16 +215,28 @@ static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
 }
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t s) {
+    int rc = STMI_OK;
+    if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) return rc;
     if (dtype == STMI_BF16) return launch_typed<bf16_t>(p, s);
     return launch_typed<float>(p, s);
 }
 
 // Name (as a profiler prints it) of the kernel instantiation a stride-1 conv forward or
 // backward-data of this geometry launches.
-void conv_kernel_name(int rows, long pixels, int dtype, char* buf, int buflen) {
+void conv_kernel_name(int rows, long pixels, int kchannels, int dtype, char* buf, int buflen) {
     static const char* cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
-    snprintf(buf, buflen, "void stmi::conv_gemm_kernel<%s, %s>(stmi::ConvGemmParams)",
-             dtype == STMI_BF16 ? "__bf16" : "float", cfg[pick_cfg(packed_rows(rows), pixels, 1)]);
+    const char* tname = dtype == STMI_BF16 ? "__bf16" : "float";
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = 1; p.Hs = 1; p.Ws = (int)pixels;
+    p.ntaps = 1; p.klen = kchannels; p.cdiv = (kchannels % 8) ? kchannels : 0;
+    p.co_pad = packed_rows(rows);
+    const char* glds = conv_gemm_glds_cfg_name(p, dtype);
+    if (glds)
+        snprintf(buf, buflen, "void stmi::conv_gemm_glds_kernel<%s, %s>(stmi::ConvGemmParams)", tname, glds);
+    else
+        snprintf(buf, buflen, "void stmi::conv_gemm_kernel<%s, %s>(stmi::ConvGemmParams)", tname,
+                 cfg[pick_cfg(p.co_pad, pixels, 1)]);
 }
 
 // rows of a packed weight set are padded so that every block tile height divides them

@@ -1,26 +1,22 @@
 // Instance normalisation for NHWC activations on gfx950 (HBM-bound).
 //
-// A thread owns V consecutive channels (16 bytes when the channel count allows)
-// and walks pixels, so every wave access is a run of whole NHWC pixel rows.
-// Statistics are two-level: per-block partial sums (shifted by the sample's
-// first pixel so that sum-of-squares stays well conditioned) written to a
-// workspace, combined in the prologue of the consuming kernel.  Nothing is
-// atomically accumulated except the per-channel parameter gradients.
+// A thread owns V consecutive channels (16 bytes when the channel count allows) and walks
+// pixels, so every wave access is a run of whole NHWC pixel rows.  Each direction is three
+// launches:
+//   partial  per-block sums over a slice of the plane (enough slices to fill the chip),
+//            shifted by the sample's first pixel so that the sum of squares stays well
+//            conditioned; written to a workspace, no atomics, bit-reproducible
+//   finalize one block per sample folds the partials into per-channel constants
+//   apply    streams the tensor once more and writes the result
+// The only atomics are the per-channel parameter gradients (summed over samples).
 #include "common.hpp"
 
 namespace stmi {
 
-constexpr int kInMaxSplits = 64;
-
-static inline int in_splits(long hw) {
-    long s = (hw + 511) / 512;
-    if (s > kInMaxSplits) s = kInMaxSplits;
-    if (s < 1) s = 1;
-    return (int)s;
-}
+constexpr int kInMaxSplits = 256;
 
 struct InGeom {
-    int N, HW, C, S, chunk;  // S splits of `chunk` pixels
+    int N, HW, C, S, chunk;  // S slices of `chunk` pixels per sample
 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -38,25 +34,24 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     return 1.f;
 }
 
-// Combines a block's per-thread partials (2V floats each) over pixel slots and
-// writes 2C floats: for channel group cg, V first-moment then V second-moment sums.
+// Folds a block's per-thread sums (two per channel) over its pixel slots and writes 2C
+// floats to dst: [c] = first sum, [C + c] = second sum.
 template <int V>
 __device__ __forceinline__ void block_combine(const float (&s1)[V], const float (&s2)[V], float* red, float* dst,
-                                              int CG, int slots, bool active) {
+                                              int C, int CG, int slots, bool active) {
     const int tid = threadIdx.x;
+    const int slot = tid / CG, cg = tid - slot * CG;
     if (active) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-            red[tid * 2 * V + j] = s1[j];
-            red[tid * 2 * V + V + j] = s2[j];
+            red[slot * 2 * C + cg * V + j] = s1[j];
+            red[slot * 2 * C + C + cg * V + j] = s2[j];
         }
     }
     __syncthreads();
-    const int total = CG * 2 * V;
-    for (int o = tid; o < total; o += 256) {
-        const int cg = o / (2 * V), j = o - cg * 2 * V;
+    for (int o = tid; o < 2 * C; o += 256) {
         float acc = 0.f;
-        for (int sl = 0; sl < slots; sl++) acc += red[(sl * CG + cg) * 2 * V + j];
+        for (int sl = 0; sl < slots; sl++) acc += red[sl * 2 * C + o];
         dst[o] = acc;
     }
 }
@@ -87,49 +82,46 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
             }
         }
     }
-    block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, CG, slots, active);
+    block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, g.C, CG, slots, active);
+}
+
+// stats[n][c] = (mean, 1/sqrt(var + eps)) from the shifted partial sums
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_finalize_kernel(const T* __restrict__ x, const float* __restrict__ ws,
+                                                                float* __restrict__ stats, float eps, InGeom g) {
+    const int n = blockIdx.x;
+    const float inv = 1.f / (float)g.HW;
+    for (int c = threadIdx.x; c < g.C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < g.S; s++) {
+            const float* w = ws + ((long)n * g.S + s) * 2 * g.C;
+            s1 += w[c];
+            s2 += w[g.C + c];
+        }
+        const float k = to_f32<T>(x[(long)n * g.HW * g.C + c]);
+        const float m = s1 * inv;
+        const float var = fmaxf(s2 * inv - m * m, 0.f);
+        stats[((long)n * g.C + c) * 2] = k + m;
+        stats[((long)n * g.C + c) * 2 + 1] = 1.f / sqrtf(var + eps);
+    }
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ ws,
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       const T* residual, T* y, float* y_f32, float* stats_out, float eps,
-                                                       int act, InGeom g) {
+                                                       const T* residual, T* y, float* y_f32, int act, InGeom g) {
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
     if (tid >= slots * CG) return;
     const int slot = tid / CG, cg = tid - slot * CG;
     const int n = blockIdx.y;
-    const T* xs = x + (long)n * g.HW * g.C;
     float a[V], b[V];
-    {
-        float k[V], s1[V], s2[V];
-        load_vec<T, V>(xs + cg * V, k);
 #pragma unroll
-        for (int j = 0; j < V; j++) s1[j] = s2[j] = 0.f;
-        for (int s = 0; s < g.S; s++) {
-            const float* w = ws + ((long)n * g.S + s) * 2 * g.C + cg * 2 * V;
-#pragma unroll
-            for (int j = 0; j < V; j++) {
-                s1[j] += w[j];
-                s2[j] += w[V + j];
-            }
-        }
-        const float inv = 1.f / (float)g.HW;
-#pragma unroll
-        for (int j = 0; j < V; j++) {
-            const float m = s1[j] * inv;
-            const float var = fmaxf(s2[j] * inv - m * m, 0.f);
-            const float mean = k[j] + m;
-            const float rstd = 1.f / sqrtf(var + eps);
-            const int c = cg * V + j;
-            a[j] = scale[c] * rstd;
-            b[j] = shift[c] - mean * a[j];
-            if (stats_out && blockIdx.x == 0 && slot == 0) {
-                stats_out[((long)n * g.C + c) * 2] = mean;
-                stats_out[((long)n * g.C + c) * 2 + 1] = rstd;
-            }
-        }
+    for (int j = 0; j < V; j++) {
+        const int c = cg * V + j;
+        const float mean = stats[((long)n * g.C + c) * 2], rstd = stats[((long)n * g.C + c) * 2 + 1];
+        a[j] = scale[c] * rstd;
+        b[j] = shift[c] - mean * a[j];
     }
     const long sample = (long)n * g.HW * g.C;
     for (int pix = blockIdx.x * slots + slot; pix < g.HW; pix += gridDim.x * slots) {
@@ -149,7 +141,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// pass 1 of the backward: per-(n,c) sums of g and g*xhat, g = dy * act'(z)
+// backward pass 1: per-(n,c) sums of g and g*xhat, g = dy * act'(z)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             const float* __restrict__ stats,
@@ -191,17 +183,35 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
             }
         }
     }
-    block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, CG, slots, active);
+    block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, g.C, CG, slots, active);
 }
 
-// pass 2: dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat)); parameter gradients added once per sample
+// backward pass 2: means[n][c] = (mean(g), mean(g*xhat)); parameter gradients summed over samples
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ means,
+                                                              float* dscale, float* dshift, InGeom g) {
+    const int n = blockIdx.x;
+    const float inv = 1.f / (float)g.HW;
+    for (int c = threadIdx.x; c < g.C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < g.S; s++) {
+            const float* w = ws + ((long)n * g.S + s) * 2 * g.C;
+            s1 += w[c];
+            s2 += w[g.C + c];
+        }
+        atomicAdd(dshift + c, s1);
+        atomicAdd(dscale + c, s2);
+        means[((long)n * g.C + c) * 2] = s1 * inv;
+        means[((long)n * g.C + c) * 2 + 1] = s2 * inv;
+    }
+}
+
+// backward pass 3: dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat))
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ ws, T* dx, float* dscale,
-                                                           float* dshift, int act, InGeom g) {
+                                                           const float* __restrict__ means, T* dx, int act, InGeom g) {
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
     if (tid >= slots * CG) return;
@@ -209,29 +219,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     const int n = blockIdx.y;
     float mean[V], rstd[V], sc[V], sh[V], m1[V], m2[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) m1[j] = m2[j] = 0.f;
-    for (int s = 0; s < g.S; s++) {
-        const float* w = ws + ((long)n * g.S + s) * 2 * g.C + cg * 2 * V;
-#pragma unroll
-        for (int j = 0; j < V; j++) {
-            m1[j] += w[j];
-            m2[j] += w[V + j];
-        }
-    }
-    const float inv = 1.f / (float)g.HW;
-#pragma unroll
     for (int j = 0; j < V; j++) {
         const int c = cg * V + j;
         mean[j] = stats[((long)n * g.C + c) * 2];
         rstd[j] = stats[((long)n * g.C + c) * 2 + 1];
+        m1[j] = means[((long)n * g.C + c) * 2];
+        m2[j] = means[((long)n * g.C + c) * 2 + 1];
         sc[j] = scale[c];
         sh[j] = shift[c];
-        if (blockIdx.x == 0 && slot == 0) {
-            atomicAdd(dshift + c, m1[j]);
-            atomicAdd(dscale + c, m2[j]);
-        }
-        m1[j] *= inv;
-        m2[j] *= inv;
     }
     const long sample = (long)n * g.HW * g.C;
     for (int pix = blockIdx.x * slots + slot; pix < g.HW; pix += gridDim.x * slots) {
@@ -249,28 +244,34 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-static InGeom make_geom(int n, int h, int w, int c) {
-    InGeom g;
-    g.N = n; g.HW = h * w; g.C = c;
-    g.S = in_splits((long)h * w);
-    g.chunk = (g.HW + g.S - 1) / g.S;
-    return g;
-}
-
-static int apply_blocks(const InGeom& g, int slots) {
-    long b = ((long)g.HW + slots * 4 - 1) / (slots * 4);  // ~4 pixels per thread
-    if (b > 512) b = 512;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
-// V = widest vector that divides C; C up to 1024 with V >= C/256
+// V = widest vector that divides C (C / V <= 256 threads)
 template <typename T>
 static int pick_v(int c) {
     constexpr int VMAX = 16 / (int)sizeof(T);
     if (c % VMAX == 0 && c / VMAX <= 256) return VMAX;
     if (c <= 256) return 1;
     return 0;
+}
+
+template <typename T>
+static InGeom make_geom(int n, int h, int w, int c) {
+    InGeom g;
+    g.N = n; g.HW = h * w; g.C = c;
+    const int v = pick_v<T>(c) > 0 ? pick_v<T>(c) : 1;
+    const int slots = 256 / (c / v);
+    long s = ((long)g.HW + slots * 8 - 1) / (slots * 8);  // ~8 pixels per thread
+    if (s > kInMaxSplits) s = kInMaxSplits;
+    if (s < 1) s = 1;
+    g.S = (int)s;
+    g.chunk = (g.HW + g.S - 1) / g.S;
+    return g;
+}
+
+static int apply_blocks(const InGeom& g, int slots) {
+    long b = ((long)g.HW + slots * 4 - 1) / (slots * 4);  // ~4 pixels per thread
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
 }
 
 #define IN_DISPATCH(T, c, ...)                                                    \
@@ -281,26 +282,32 @@ static int pick_v(int c) {
         else { set_error("instance norm: unsupported channel count %d", c); return STMI_ERR_INVALID; } \
     } while (0)
 
+// workspace layout (floats): [N*S*2C partial sums][N*C*2 backward means]
+static inline long partial_floats(int n, int c) { return (long)n * kInMaxSplits * 2 * c; }
+long in_ws_floats(int n, int h, int w, int c) { return partial_floats(n, c) + (long)n * c * 2; }
+
 template <typename T>
-static int stats_typed(const void* x, float* ws, int n, int h, int w, int c, hipStream_t s) {
-    const InGeom g = make_geom(n, h, w, c);
+static int stats_typed(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, hipStream_t s) {
+    const InGeom g = make_geom<T>(n, h, w, c);
     IN_DISPATCH(T, c, {
-        hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), 256 * 2 * V * sizeof(float), s,
+        const int slots = 256 / (c / V);
+        hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, ws, g);
     });
-    STMI_LAUNCH_CHECK("in_stats_kernel");
+    hipLaunchKernelGGL((in_stats_finalize_kernel<T>), dim3(n), dim3(256), 0, s, (const T*)x, ws, stats, eps, g);
+    STMI_LAUNCH_CHECK("in_stats kernels");
     return STMI_OK;
 }
 
 template <typename T>
-static int apply_typed(const void* x, const float* ws, const float* scale, const float* shift, const void* residual,
-                       void* y, float* y_f32, float* stats_out, float eps, int act, int n, int h, int w, int c,
+static int apply_typed(const void* x, const float* stats, const float* scale, const float* shift,
+                       const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c,
                        hipStream_t s) {
-    const InGeom g = make_geom(n, h, w, c);
+    const InGeom g = make_geom<T>(n, h, w, c);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
-        hipLaunchKernelGGL((in_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x, ws,
-                           scale, shift, (const T*)residual, (T*)y, y_f32, stats_out, eps, act, g);
+        hipLaunchKernelGGL((in_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x,
+                           stats, scale, shift, (const T*)residual, (T*)y, y_f32, act, g);
     });
     STMI_LAUNCH_CHECK("in_apply_kernel");
     return STMI_OK;
@@ -310,30 +317,30 @@ template <typename T>
 static int bwd_typed(const void* x, const void* dy, const float* stats, const float* scale, const float* shift,
                      void* dx, float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c,
                      hipStream_t s) {
-    const InGeom g = make_geom(n, h, w, c);
+    const InGeom g = make_geom<T>(n, h, w, c);
+    float* means = ws + partial_floats(n, c);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
-        hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), 256 * 2 * V * sizeof(float), s,
+        hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, (const T*)dy, stats, scale, shift, ws, act, g);
+        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(n), dim3(256), 0, s, (const float*)ws, means, dscale, dshift, g);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x,
-                           (const T*)dy, stats, scale, shift, ws, (T*)dx, dscale, dshift, act, g);
+                           (const T*)dy, stats, scale, shift, (const float*)means, (T*)dx, act, g);
     });
     STMI_LAUNCH_CHECK("in_bwd kernels");
     return STMI_OK;
 }
 
-long in_ws_floats(int n, int h, int w, int c) { return (long)n * kInMaxSplits * 2 * c; }
-
-int in_stats_impl(const void* x, float* ws, int n, int h, int w, int c, int dtype, hipStream_t s) {
-    return dtype == STMI_BF16 ? stats_typed<bf16_t>(x, ws, n, h, w, c, s) : stats_typed<float>(x, ws, n, h, w, c, s);
+int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
+                  hipStream_t s) {
+    return dtype == STMI_BF16 ? stats_typed<bf16_t>(x, ws, stats, eps, n, h, w, c, s)
+                              : stats_typed<float>(x, ws, stats, eps, n, h, w, c, s);
 }
 
-int in_apply_impl(const void* x, const float* ws, const float* scale, const float* shift, const void* residual,
-                  void* y, float* y_f32, float* stats_out, float eps, int act, int n, int h, int w, int c, int dtype,
-                  hipStream_t s) {
-    return dtype == STMI_BF16
-               ? apply_typed<bf16_t>(x, ws, scale, shift, residual, y, y_f32, stats_out, eps, act, n, h, w, c, s)
-               : apply_typed<float>(x, ws, scale, shift, residual, y, y_f32, stats_out, eps, act, n, h, w, c, s);
+int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
+                  void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s) {
+    return dtype == STMI_BF16 ? apply_typed<bf16_t>(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, s)
+                              : apply_typed<float>(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
 }
 
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,

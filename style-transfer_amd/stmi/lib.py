@@ -22,7 +22,7 @@ SIGNATURES = {
     'stmi_version': (_c_int, []),
     'stmi_last_error': (ctypes.c_char_p, []),
     'stmi_device_arch': (_c_int, [ctypes.c_char_p, _c_int]),
-    'stmi_conv_kernel_name': (_c_int, [_c_int, _c_long, _c_int, ctypes.c_char_p, _c_int]),
+    'stmi_conv_kernel_name': (_c_int, [_c_int, _c_long, _c_int, _c_int, ctypes.c_char_p, _c_int]),
     'stmi_conv_packed_elems': (_c_long, [_c_int] * 5),
     'stmi_pack_conv_weights': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + _CONV + [_c_int, _c_int, _vp]),
@@ -32,8 +32,8 @@ SIGNATURES = {
     'stmi_conv2d_transpose_nhwc_dgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
     'stmi_instance_norm_ws_floats': (_c_long, [_c_int] * 4),
-    'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
-    'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 8 + [_c_float] + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
+    'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),
     'stmi_maxpool2x2_same_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),

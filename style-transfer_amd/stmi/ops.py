@@ -50,19 +50,19 @@ def same_out(size, stride):
 PROFILE = None
 
 
-def _kernel_name(out_channels, out_pixels, dtype_code):
+def _kernel_name(out_channels, out_pixels, k_channels, dtype_code):
     import ctypes
     buf = ctypes.create_string_buffer(256)
-    _lib.call('stmi_conv_kernel_name', out_channels, out_pixels, dtype_code, buf, 256)
+    _lib.call('stmi_conv_kernel_name', out_channels, out_pixels, k_channels, dtype_code, buf, 256)
     return buf.value.decode()
 
 
 class _Timed:
-    def __init__(self, out_channels, out_pixels, k_total, dtype_code, stride):
+    def __init__(self, out_channels, out_pixels, k_channels, taps, dtype_code, stride):
         self.on = PROFILE is not None and stride == 1
         if self.on:
-            self.name = _kernel_name(out_channels, out_pixels, dtype_code)
-            self.flops = 2.0 * out_channels * out_pixels * k_total
+            self.name = _kernel_name(out_channels, out_pixels, k_channels, dtype_code)
+            self.flops = 2.0 * out_channels * out_pixels * k_channels * taps
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
 
@@ -108,7 +108,7 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
         pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', x.dtype, oshape)
     if bias is not None:
         _chk(bias, 'bias', torch.float32, (co,))
-    with _Timed(co, n * oshape[1] * oshape[2], kh * kw * ci, _dt(x), stride):
+    with _Timed(co, n * oshape[1] * oshape[2], ci, kh * kw, _dt(x), stride):
         _lib.call('stmi_conv2d_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
                   n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x), _stream())
     return (y, pre) if want_pre else y
@@ -126,7 +126,7 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
     for t, nm in ((relu_mask, 'relu_mask'), (addend, 'addend')):
         if t is not None:
             _chk(t, nm, dy.dtype, oshape)
-    with _Timed(ci, n * h * w, kh * kw * co, _dt(dy), stride):
+    with _Timed(ci, n * h * w, co, kh * kw, _dt(dy), stride):
         _lib.call('stmi_conv2d_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
                   _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
     return dx
@@ -213,9 +213,10 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
     if residual is not None:
         _chk(residual, 'residual', x.dtype, x.shape)
     s = _stream()
-    _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), n, h, w, c, _dt(x), s)
-    _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), ws.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-              _ptr(residual), y.data_ptr(), _ptr(y32), stats.data_ptr(), float(eps), act, n, h, w, c, _dt(x), s)
+    _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps),
+              n, h, w, c, _dt(x), s)
+    _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), stats.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              _ptr(residual), y.data_ptr(), _ptr(y32), act, n, h, w, c, _dt(x), s)
     return (y, stats, y32) if want_f32 else (y, stats)
 
 

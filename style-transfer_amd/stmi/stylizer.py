@@ -103,7 +103,7 @@ class StylizerNet:
                                             self.grad_views[3 * i + 2])
                 b.conv_out = torch.empty(oshape, dtype=dtype, device=device)
                 b.y = torch.empty(oshape, dtype=dtype, device=device)
-            ws_floats = max(ws_floats, batch * 64 * 2 * co)
+            ws_floats = max(ws_floats, ops._lib.load().stmi_instance_norm_ws_floats(batch, b.out_h, b.out_w, co))
             self.blocks.append(b)
             h, w, c = b.out_h, b.out_w, co
         self.out_f32 = torch.empty((batch, h, w, 3), dtype=torch.float32, device=device)
