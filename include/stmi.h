@@ -41,6 +41,8 @@ extern "C" {
 /* which GEMM a packed weight buffer feeds */
 #define STMI_PACK_FWD 0   /* conv forward; transposed-conv backward-data */
 #define STMI_PACK_DGRAD 1 /* conv backward-data; transposed-conv forward */
+#define STMI_PACK_FWD_ROWOUT 2 /* conv forward producing (kx, co) row patches, kw*co <= 32: packed like
+                                * the STMI_PACK_FWD weights of a [kh,1,ci,32] conv (see row patches below) */
 
 /* ---- library ---------------------------------------------------------- */
 int stmi_version(void);
@@ -180,6 +182,28 @@ int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight
 int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count,
                   float lr, float beta1, float beta2, float eps, float grad_scale,
                   int* step_dev, int t, void* stream);
+
+/* ---- row patches for layers with < 8 channels on one side (the 9x9 RGB layers) ----------
+ * A kw x c window of an NHWC tensor is kw*c contiguous elements.  Copying it once per pixel
+ * into a 32-wide row turns the [kh,kw] convolution into kh vertical taps with 32 reduction
+ * channels (or 32 outputs), which the GEMM kernels run without padding waste:
+ *   conv c->co   : rows = pixels_to_rows(x, dx0=-pad_left); y = conv2d_fwd(rows, [kh,1,32,co]) with the
+ *                  STMI_PACK_FWD weights of the original kernel; dW = rows_wgrad_to_hwio(mode 0) of
+ *                  conv2d_wgrad(rows, dy, [kh,1,32,co])
+ *   conv ci->c   : t = conv2d_fwd(x, [kh,1,ci,32]) with STMI_PACK_FWD_ROWOUT weights;
+ *                  y = rows_to_pixels_sum(t, dx0=-pad_left);
+ *                  r = pixels_to_rows(dy, dx0=pad_left-(kw-1)); dx = conv2d_dgrad(r, [kh,1,ci,32]) with the
+ *                  STMI_PACK_DGRAD weights of the original kernel; dW = rows_wgrad_to_hwio(mode 1) of
+ *                  conv2d_wgrad(x, r, [kh,1,ci,32])
+ * pixels_to_rows   : rows[n,y,x,e] = x[n,y,x+dx0+e/c,e%c] for e < kw*c and an in-range column, else 0
+ * rows_to_pixels_sum: y[n,yy,x,co] = sum_kx rows[n,yy,x+dx0+kx,kx*c+co] over in-range columns */
+int stmi_pixels_to_rows(const void* x, void* rows, int n, int h, int w, int c, int kw, int dx0,
+                        int dtype, void* stream);
+int stmi_rows_to_pixels_sum(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0,
+                            int dtype, void* stream);
+/* d fp32 is the [kh,1,32,co] (mode 0) or [kh,1,ci,32] (mode 1) gradient of the row-patch conv;
+ * dw fp32 [kh,kw,ci,co] is the gradient of the original kernel, overwritten. */
+int stmi_rows_wgrad_to_hwio(const float* d, float* dw, int kh, int kw, int ci, int co, int mode, void* stream);
 
 /* ---- small utilities --------------------------------------------------- */
 /* dtype conversion between fp32 and `dtype`; to_f32 != 0 converts dtype -> fp32 */

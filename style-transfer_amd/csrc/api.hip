@@ -43,6 +43,9 @@ int scale_shift_impl(const float*, const float*, void*, float, long, int, int, h
 int cast_impl(const void*, void*, long, int, int, hipStream_t);
 int clip_impl(float*, long, float, float, hipStream_t);
 int activation_impl(const void*, void*, long, int, int, hipStream_t);
+int pixels_to_rows_impl(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int rows_to_pixels_sum_impl(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int rows_wgrad_to_hwio_impl(const float*, float*, int, int, int, int, int, hipStream_t);
 int pool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
 int pool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 int mse_impl(const void*, const void*, void*, float*, float, float, long, int, hipStream_t);
@@ -103,7 +106,10 @@ long stmi_conv_packed_elems(int kh, int kw, int ci, int co, int mode) {
 int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, int ci, int co, int mode, int dtype,
                            void* stream) {
     if (check_conv("pack_conv_weights", 0, 1, 1, ci, co, kh, kw, 1, dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(mode == STMI_PACK_FWD || mode == STMI_PACK_DGRAD, "pack_conv_weights: bad mode %d", mode);
+    STMI_REQUIRE(mode == STMI_PACK_FWD || mode == STMI_PACK_DGRAD || mode == STMI_PACK_FWD_ROWOUT,
+                 "pack_conv_weights: bad mode %d", mode);
+    STMI_REQUIRE(mode != STMI_PACK_FWD_ROWOUT || (kw * co <= 32 && ci % 8 == 0),
+                 "pack_conv_weights: row-patch output needs kw*co <= 32 and ci %% 8 == 0 (kw=%d co=%d ci=%d)", kw, co, ci);
     STMI_REQUIRE(w_hwio && packed, "pack_conv_weights: null pointer");
     return pack_weights_impl(w_hwio, packed, kh, kw, ci, co, mode, dtype, S(stream));
 }
@@ -266,6 +272,28 @@ int stmi_cast(const void* src, void* dst, long count, int dtype, int to_f32, voi
     STMI_REQUIRE(src && dst && count >= 0, "cast: bad arguments");
     if (count == 0) return STMI_OK;
     return cast_impl(src, dst, count, dtype, to_f32, S(stream));
+}
+
+int stmi_pixels_to_rows(const void* x, void* rows, int n, int h, int w, int c, int kw, int dx0, int dtype,
+                        void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && rows && n >= 0 && h > 0 && w > 0 && c > 0 && kw > 0 && kw * c <= 32, "pixels_to_rows: bad arguments");
+    if (n == 0) return STMI_OK;
+    return pixels_to_rows_impl(x, rows, n, h, w, c, kw, dx0, dtype, S(stream));
+}
+
+int stmi_rows_to_pixels_sum(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
+                            void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(rows && y && n >= 0 && h > 0 && w > 0 && c > 0 && kw > 0 && kw * c <= 32, "rows_to_pixels_sum: bad arguments");
+    if (n == 0) return STMI_OK;
+    return rows_to_pixels_sum_impl(rows, y, n, h, w, c, kw, dx0, dtype, S(stream));
+}
+
+int stmi_rows_wgrad_to_hwio(const float* d, float* dw, int kh, int kw, int ci, int co, int mode, void* stream) {
+    STMI_REQUIRE(d && dw && kh > 0 && kw > 0 && ci > 0 && co > 0 && (mode == 0 || mode == 1), "rows_wgrad_to_hwio: bad arguments");
+    STMI_REQUIRE(mode == 0 ? kw * ci <= 32 : kw * co <= 32, "rows_wgrad_to_hwio: the patched side must fit 32 columns");
+    return rows_wgrad_to_hwio_impl(d, dw, kh, kw, ci, co, mode, S(stream));
 }
 
 int stmi_activation(const void* x, void* y, long count, int act, int dtype, void* stream) {

@@ -252,6 +252,15 @@ static bool row_mode(int kchannels) { return (kchannels % 8) != 0; }
 // mode FWD : rows = co, K = ci     mode DGRAD: rows = ci, K = co
 PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
     PackGeom g;
+    if (mode == STMI_PACK_FWD_ROWOUT) {  // rows = (kx, co) pairs, one vertical tap per ky, K = ci
+        g.rows = kw * co;
+        g.rows_pad = packed_rows(g.rows);
+        g.row = false;
+        g.ntaps = kh;
+        g.klen = ci;
+        g.kpad = round_up(ci, 32);
+        return g;
+    }
     const int kch = mode == STMI_PACK_FWD ? ci : co;
     g.rows = mode == STMI_PACK_FWD ? co : ci;
     g.rows_pad = packed_rows(g.rows);
@@ -271,7 +280,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
         const int row = (int)((idx / g.kpad) % g.rows_pad);
         const int t = (int)(idx / ((long)g.kpad * g.rows_pad));
         float v = 0.f;
-        if (row < g.rows && e < g.klen) {
+        if (mode == STMI_PACK_FWD_ROWOUT) {
+            if (row < g.rows && e < g.klen) v = w[(((long)t * kw + row / co) * ci + e) * co + row % co];
+        } else if (row < g.rows && e < g.klen) {
             int ky, kx, kc;
             const int kch = mode == STMI_PACK_FWD ? ci : co;
             if (g.row) {

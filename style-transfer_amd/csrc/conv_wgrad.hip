@@ -13,6 +13,8 @@
 // atomic adds into a zeroed output.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace stmi {
 
 struct WgradParams {
@@ -232,7 +234,9 @@ static int launch_wg(WgradParams& p, hipStream_t s) {
     const long pix_total = batched ? (long)p.Ho * p.Wo : (long)p.N * p.Ho * p.Wo;
     const int rtiles = ceil_div(p.klen, BLK_R), ctiles = ceil_div(p.Co, BLK_C);
     const long tiles = (long)p.ntaps * rtiles * ctiles * (batched ? p.N : 1);
-    long splits = (1024 + tiles - 1) / tiles;
+    const char* tb = getenv("STMI_WG_BLOCKS");
+    const long target = tb ? atol(tb) : (batched ? 512 : 1024);
+    long splits = (target + tiles - 1) / tiles;
     const long max_splits = (pix_total + 4 * BKP - 1) / (4 * BKP);  // at least 4 steps per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -249,7 +253,17 @@ static int launch_wg(WgradParams& p, hipStream_t s) {
 
 template <typename T>
 static int launch_wg_typed(WgradParams& p, hipStream_t s) {
-    if (p.klen > 64 && p.Co > 64) return launch_wg<T, 4, 4, 2, 2>(p, s);  // 128 x 128
+    if (const char* f = getenv("STMI_WG_CFG")) {
+        switch (atoi(f)) {
+            case 0: return launch_wg<T, 4, 4, 2, 2>(p, s);
+            case 1: return launch_wg<T, 2, 2, 2, 2>(p, s);
+            case 2: return launch_wg<T, 2, 1, 4, 1>(p, s);
+            case 3: return launch_wg<T, 1, 2, 1, 4>(p, s);
+            case 4: return launch_wg<T, 1, 1, 2, 2>(p, s);
+        }
+    }
+    // At the batch sizes of this path the pixel reduction is short, so the partial-tile atomics
+    // dominate: 64 x 64 tiles (4x fewer atomic bytes per covered pixel than 128 x 128) win.
     if (p.klen > 32 && p.Co > 32) return launch_wg<T, 2, 2, 2, 2>(p, s);  // 64 x 64
     if (p.klen > 32) return launch_wg<T, 2, 1, 4, 1>(p, s);               // 128 x 16
     if (p.Co > 32) return launch_wg<T, 1, 2, 1, 4>(p, s);                 // 16 x 128

@@ -318,3 +318,102 @@ int adam_impl(float* p, const float* g, float* m, float* v, long count, float lr
 }
 
 }  // namespace stmi
+
+// ---------------------------------------------------------------------------
+// Row patches for layers with very few channels on one side (the 9x9 RGB layers).
+// A kw x C window of a C-channel NHWC tensor is kw*C CONTIGUOUS elements; copying it out
+// once per pixel into a 32-wide row turns the kw x kh convolution into kh vertical taps
+// with K = 32 (or 32 outputs), which the GEMM kernels run at full MFMA efficiency.
+// ---------------------------------------------------------------------------
+namespace stmi {
+
+// rows[n,y,x,e] = x[n, y, x + dx0 + e/c, e%c] for e < kw*c and an in-range column, else 0
+template <typename T>
+__global__ void pixels_to_rows_kernel(const T* __restrict__ x, T* __restrict__ rows, int n, int h, int w, int c,
+                                      int kw, int dx0) {
+    const long total = (long)n * h * w * 4;  // 4 chunks of 8 elements per pixel
+    const int klen = kw * c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int chunk = (int)(i & 3);
+        const long pix = i >> 2;
+        const int xx = (int)(pix % w);
+        const long rowbase = (pix - xx) * c;  // element offset of column 0 of this image row
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = chunk * 8 + u;
+            const int col = xx + dx0 + e / c;
+            v[u] = (e < klen && (unsigned)col < (unsigned)w) ? to_f32<T>(x[rowbase + (long)(xx + dx0) * c + e]) : 0.f;
+        }
+        if constexpr (sizeof(T) == 2) {
+            store_vec<T, 8>(rows + pix * 32 + chunk * 8, v);
+        } else {
+            float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+            store_vec<T, 4>(rows + pix * 32 + chunk * 8, lo);
+            store_vec<T, 4>(rows + pix * 32 + chunk * 8 + 4, hi);
+        }
+    }
+}
+
+// y[n,yy,x,co] = sum_kx rows[n, yy, x + dx0 + kx, kx*c + co] over in-range columns
+template <typename T>
+__global__ void rows_to_pixels_sum_kernel(const T* __restrict__ rows, T* __restrict__ y, int n, int h, int w, int c,
+                                          int kw, int dx0) {
+    const long total = (long)n * h * w * c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % c);
+        const long pix = i / c;
+        const int xx = (int)(pix % w);
+        float acc = 0.f;
+        for (int kx = 0; kx < kw; kx++) {
+            const int col = xx + dx0 + kx;
+            if ((unsigned)col < (unsigned)w) acc += to_f32<T>(rows[(pix + dx0 + kx) * 32 + kx * c + co]);
+        }
+        y[i] = from_f32<T>(acc);
+    }
+}
+
+// mode 0: dw[ky][e][co]             = d[ky][e][co]            (e < kw*c; rows on the reduction side)
+// mode 1: dw[ky][kw-1-j][ci][co]    = d[ky][ci][j*co_n + co]  (rows on the output side)
+__global__ void rows_wgrad_to_hwio_kernel(const float* __restrict__ d, float* __restrict__ dw, int kh, int kw, int ci,
+                                          int co, int mode) {
+    const int total = kh * kw * ci * co;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i % co;
+        const int c = (i / co) % ci;
+        const int kx = (i / (co * ci)) % kw;
+        const int ky = i / (co * ci * kw);
+        dw[i] = mode == 0 ? d[((long)ky * 32 + kx * ci + c) * co + o]
+                          : d[((long)ky * ci + c) * 32 + (kw - 1 - kx) * co + o];
+    }
+}
+
+int pixels_to_rows_impl(const void* x, void* rows, int n, int h, int w, int c, int kw, int dx0, int dtype,
+                        hipStream_t s) {
+    const dim3 grid(flat_blocks((long)n * h * w * 4));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(pixels_to_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)rows, n, h, w, c, kw, dx0);
+    else
+        hipLaunchKernelGGL(pixels_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)rows, n, h, w, c, kw, dx0);
+    STMI_LAUNCH_CHECK("pixels_to_rows_kernel");
+    return STMI_OK;
+}
+
+int rows_to_pixels_sum_impl(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
+                            hipStream_t s) {
+    const dim3 grid(flat_blocks((long)n * h * w * c));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)rows, (bf16_t*)y, n, h, w, c, kw, dx0);
+    else
+        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<float>, grid, dim3(256), 0, s, (const float*)rows, (float*)y, n, h, w, c, kw, dx0);
+    STMI_LAUNCH_CHECK("rows_to_pixels_sum_kernel");
+    return STMI_OK;
+}
+
+int rows_wgrad_to_hwio_impl(const float* d, float* dw, int kh, int kw, int ci, int co, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(rows_wgrad_to_hwio_kernel, dim3(flat_blocks((long)kh * kw * ci * co)), dim3(256), 0, s, d, dw, kh, kw, ci, co, mode);
+    STMI_LAUNCH_CHECK("rows_wgrad_to_hwio_kernel");
+    return STMI_OK;
+}
+
+}  // namespace stmi

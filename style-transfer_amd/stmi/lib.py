@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, '..', 'libstmi355.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-PACK_FWD, PACK_DGRAD = 0, 1
+PACK_FWD, PACK_DGRAD, PACK_FWD_ROWOUT = 0, 1, 2
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -46,6 +46,9 @@ SIGNATURES = {
     'stmi_tv_loss_fwd_bwd': (_c_int, [_vp] * 3 + [_c_float] + [_c_int] * 5 + [_vp]),
     'stmi_adam_tf1': (_c_int, [_vp] * 4 + [_c_long] + [_c_float] * 5 + [_vp, _c_int, _vp]),
     'stmi_cast': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
+    'stmi_pixels_to_rows': (_c_int, [_vp, _vp] + [_c_int] * 7 + [_vp]),
+    'stmi_rows_to_pixels_sum': (_c_int, [_vp, _vp] + [_c_int] * 7 + [_vp]),
+    'stmi_rows_wgrad_to_hwio': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_activation': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_clip': (_c_int, [_vp, _c_long, _c_float, _c_float, _vp]),
 }

@@ -8,7 +8,7 @@ Tensors are NHWC, contiguous, on the current HIP device, float32 or bfloat16.
 import torch
 
 from . import lib as _lib
-from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD  # noqa: F401
+from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD, PACK_FWD_ROWOUT  # noqa: F401
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -184,6 +184,35 @@ def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None):
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
     _lib.call('stmi_conv2d_transpose_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co,
               kh, kw, stride, _dt(x), _stream())
+    return dw
+
+
+# ------------------------------------------------------------ row patches
+def pixels_to_rows(x, kw, dx0, out=None):
+    """[n,h,w,c] (kw*c <= 32) -> [n,h,w,32]: the kw x c window starting dx0 columns from each pixel."""
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    oshape = (n, h, w, 32)
+    r = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    _lib.call('stmi_pixels_to_rows', x.data_ptr(), r.data_ptr(), n, h, w, c, kw, dx0, _dt(x), _stream())
+    return r
+
+
+def rows_to_pixels_sum(rows, c, kw, dx0, out=None):
+    n, h, w, k = rows.shape
+    assert k == 32
+    _chk(rows, 'rows')
+    oshape = (n, h, w, c)
+    y = torch.empty(oshape, dtype=rows.dtype, device=rows.device) if out is None else _chk(out, 'out', rows.dtype, oshape)
+    _lib.call('stmi_rows_to_pixels_sum', rows.data_ptr(), y.data_ptr(), n, h, w, c, kw, dx0, _dt(rows), _stream())
+    return y
+
+
+def rows_wgrad_to_hwio(d, kshape, mode, out=None):
+    kh, kw, ci, co = kshape
+    _chk(d, 'd', torch.float32, (kh, 1, 32, co) if mode == 0 else (kh, 1, ci, 32))
+    dw = torch.empty(kshape, dtype=torch.float32, device=d.device) if out is None else _chk(out, 'out', torch.float32, kshape)
+    _lib.call('stmi_rows_wgrad_to_hwio', d.data_ptr(), dw.data_ptr(), kh, kw, ci, co, mode, _stream())
     return dw
 
 

@@ -91,6 +91,22 @@ class StylizerNet:
                 b.out_h, b.out_w = ops.same_out(h, s), ops.same_out(w, s)
                 fwd_mode, bwd_mode = ops.PACK_FWD, ops.PACK_DGRAD
                 pk = (k, k, c, co)
+            # 9x9 layers with 3 channels on one side run as 9 vertical taps over 32-wide row
+            # patches ('in': patches of the input; 'out': the conv emits (kx, co) patches)
+            b.rows = None
+            if kind == 'conv' and s == 1:
+                if c % 8 != 0 and k * c <= 32 and i == 0:
+                    b.rows = 'in'
+                elif co % 8 != 0 and k * co <= 32 and c % 8 == 0:
+                    b.rows = 'out'
+                    fwd_mode = ops.PACK_FWD_ROWOUT
+            if b.rows:
+                b.pad_left = (k - 1) // 2
+                b.rows_buf = torch.empty((batch, h, w, 32), dtype=dtype, device=device)
+                if training:
+                    b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
+                                         device=device)
+                    b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
             b.fwd_mode, b.bwd_mode = fwd_mode, bwd_mode
             b.W, b.shift, b.scale = self.views[3 * i], self.views[3 * i + 1], self.views[3 * i + 2]
             b.wp_fwd = torch.empty(ops.packed_elems(*pk, fwd_mode), dtype=dtype, device=device)
@@ -156,6 +172,12 @@ class StylizerNet:
                 conv_out, y = self._view(free[0], b), self._view(free[1], b)
             if b.kind == 'deconv':
                 ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+            elif b.rows == 'in':
+                ops.pixels_to_rows(cur, b.k, -b.pad_left, out=b.rows_buf)
+                ops.conv2d_fwd(b.rows_buf, b.wp_fwd, (b.k, 1, 32, b.co), 1, out=conv_out)
+            elif b.rows == 'out':
+                ops.conv2d_fwd(cur, b.wp_fwd, (b.k, 1, b.ci, 32), 1, out=b.rows_buf)
+                ops.rows_to_pixels_sum(b.rows_buf, b.co, b.k, -b.pad_left, out=conv_out)
             else:
                 ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
             if b.role == 'a':
@@ -195,8 +217,16 @@ class StylizerNet:
                 pending_skip = g  # d(block input) receives d(block output) unchanged
             ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act,
                                   ws=self.ws, out=dconv)
+            rows_g = None
             if b.kind == 'deconv':
                 ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
+            elif b.rows == 'in':      # rows_buf still holds the forward's input patches
+                ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
+                ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
+            elif b.rows == 'out':
+                rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
+                ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
+                ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             else:
                 ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
             if i == 0:
@@ -206,6 +236,8 @@ class StylizerNet:
             addend = pending_skip if b.role == 'a' else None
             if b.kind == 'deconv':
                 ops.conv2d_transpose_dgrad(dconv, b.wp_bwd, b.kshape, b.s, addend=addend, out=dx)
+            elif rows_g is not None:
+                ops.conv2d_dgrad(rows_g, b.wp_bwd, (b.k, 1, b.ci, 32), 1, (b.in_h, b.in_w), addend=addend, out=dx)
             else:
                 ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx)
             if b.role == 'a':
