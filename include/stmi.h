@@ -64,6 +64,15 @@ long stmi_conv_packed_elems(int kh, int kw, int ci, int co, int mode);
 int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, int ci, int co,
                            int mode, int dtype, void* stream);
 
+/* Packs n weight tensors that live at element offsets src_off of one fp32 buffer into element
+ * offsets dst_off of one packed buffer, in one launch (descs is a HOST array, read during the call). */
+typedef struct {
+    long src_off, dst_off;
+    int kh, kw, ci, co, mode, reserved;
+} stmi_pack_desc;
+int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const stmi_pack_desc* descs, int n,
+                                 int dtype, void* stream);
+
 /* ---- convolution ------------------------------------------------------- */
 /* tf.nn.conv2d(x, W, [1,s,s,1], 'SAME')            (model_utilities.py:236-237)
  * + tf.nn.bias_add                                 (model_utilities.py:163-164)
@@ -85,10 +94,12 @@ int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
                            int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                            int dtype, void* stream);
 
-/* Gradient w.r.t. W (Conv2DBackpropFilter): dw fp32 [kh,kw,ci,co], overwritten. */
+/* Gradient w.r.t. W (Conv2DBackpropFilter): dw fp32 [kh,kw,ci,co].  accumulate == 0: dw is
+ * overwritten (zeroed here first); accumulate != 0: the gradient is ADDED to dw, which the
+ * caller has zeroed (a trainer clears its whole flat gradient buffer once per step). */
 int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw,
                            int n, int h, int w, int ci, int co, int kh, int kw, int stride,
-                           int dtype, void* stream);
+                           int accumulate, int dtype, void* stream);
 
 /* tf.nn.conv2d_transpose(x, W, [n,s*h,s*w,co], [1,s,s,1], 'SAME') with
  * W [kh,kw,co,ci]                                   (model_utilities.py:246-248)
@@ -103,10 +114,10 @@ int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, v
                                      const void* addend,
                                      int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                      int dtype, void* stream);
-/* dw fp32 [kh,kw,co,ci], overwritten. */
+/* dw fp32 [kh,kw,co,ci]; accumulate as above. */
 int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
                                      int n, int h, int w, int ci, int co, int kh, int kw, int stride,
-                                     int dtype, void* stream);
+                                     int accumulate, int dtype, void* stream);
 
 /* ---- instance norm ----------------------------------------------------- */
 /* tf.nn.moments(x,[1,2]) ; scale*(x-mu)/(var+eps)**.5 + shift   (model_utilities.py:282-288)

@@ -23,12 +23,13 @@ int check_hip(hipError_t e, const char* what) {
 // implemented in the kernel translation units
 void conv_kernel_name(int rows, long pixels, int kchannels, int dtype, char* buf, int buflen);
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
+int pack_weights_multi_impl(const float*, void*, const stmi_pack_desc*, int, int, hipStream_t);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
 int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
-                    int stride, int dtype, hipStream_t s);
+                    int stride, int accumulate, int dtype, hipStream_t s);
 int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s);
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
@@ -114,6 +115,22 @@ int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, in
     return pack_weights_impl(w_hwio, packed, kh, kw, ci, co, mode, dtype, S(stream));
 }
 
+int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const stmi_pack_desc* descs, int n, int dtype,
+                                 void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(src_base && dst_base && descs && n >= 0, "pack_conv_weights_multi: bad arguments");
+    for (int i = 0; i < n; i++) {
+        const stmi_pack_desc& d = descs[i];
+        if (check_conv("pack_conv_weights_multi", 0, 1, 1, d.ci, d.co, d.kh, d.kw, 1, dtype)) return STMI_ERR_INVALID;
+        STMI_REQUIRE(d.mode >= STMI_PACK_FWD && d.mode <= STMI_PACK_FWD_ROWOUT && d.src_off >= 0 && d.dst_off >= 0,
+                     "pack_conv_weights_multi: bad descriptor %d", i);
+        STMI_REQUIRE(d.mode != STMI_PACK_FWD_ROWOUT || (d.kw * d.co <= 32 && d.ci % 8 == 0),
+                     "pack_conv_weights_multi: descriptor %d: row-patch output needs kw*co <= 32 and ci %% 8 == 0", i);
+    }
+    if (n == 0) return STMI_OK;
+    return pack_weights_multi_impl(src_base, dst_base, descs, n, dtype, S(stream));
+}
+
 int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre, int n,
                          int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_fwd", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
@@ -130,10 +147,10 @@ int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
 }
 
 int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh,
-                           int kw, int stride, int dtype, void* stream) {
+                           int kw, int stride, int accumulate, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && dw, "conv2d_nhwc_wgrad: null pointer");
-    return conv_wgrad_impl(x, dy, dw, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
+    return conv_wgrad_impl(x, dy, dw, n, h, w, ci, co, kh, kw, stride, accumulate, dtype, S(stream));
 }
 
 // A transposed conv x[n,h,w,ci] -> y[n,sh,sw,co] with W[kh,kw,co,ci] is the backward-data of the
@@ -154,10 +171,10 @@ int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, v
 }
 
 int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co,
-                                     int kh, int kw, int stride, int dtype, void* stream) {
+                                     int kh, int kw, int stride, int accumulate, int dtype, void* stream) {
     if (check_conv("conv2d_transpose_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && dw, "conv2d_transpose_nhwc_wgrad: null pointer");
-    return conv_wgrad_impl(dy, x, dw, n, h * stride, w * stride, co, ci, kh, kw, stride, dtype, S(stream));
+    return conv_wgrad_impl(dy, x, dw, n, h * stride, w * stride, co, ci, kh, kw, stride, accumulate, dtype, S(stream));
 }
 
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c) { return in_ws_floats(n, h, w, c); }

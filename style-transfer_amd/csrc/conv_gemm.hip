@@ -272,10 +272,10 @@ PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
 }
 
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int kh, int kw, int ci, int co,
-                                    int mode, PackGeom g) {
+__device__ __forceinline__ void pack_range(const float* __restrict__ w, T* __restrict__ out, int kh, int kw, int ci,
+                                           int co, int mode, const PackGeom& g, long first, long stride) {
     const long total = (long)g.ntaps * g.rows_pad * g.kpad;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = first; idx < total; idx += stride) {
         const int e = (int)(idx % g.kpad);
         const int row = (int)((idx / g.kpad) % g.rows_pad);
         const int t = (int)(idx / ((long)g.kpad * g.rows_pad));
@@ -303,6 +303,52 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
         }
         out[idx] = from_f32<T>(v);
     }
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int kh, int kw, int ci, int co,
+                                    int mode, PackGeom g) {
+    pack_range<T>(w, out, kh, kw, ci, co, mode, g, blockIdx.x * (long)blockDim.x + threadIdx.x,
+                  (long)gridDim.x * blockDim.x);
+}
+
+// Several weight tensors of one flat fp32 buffer in one launch; the table travels by value
+// in the kernel arguments, so a captured graph replays it without any device-side table.
+constexpr int kMaxPackBatch = 48;
+struct PackEntry {
+    long src_off, dst_off;
+    int kh, kw, ci, co, mode;
+    PackGeom g;
+};
+struct PackBatch {
+    PackEntry e[kMaxPackBatch];
+};
+
+template <typename T>
+__global__ void pack_weights_multi_kernel(const float* __restrict__ src, T* __restrict__ dst, const PackBatch b) {
+    const PackEntry& d = b.e[blockIdx.y];
+    pack_range<T>(src + d.src_off, dst + d.dst_off, d.kh, d.kw, d.ci, d.co, d.mode, d.g,
+                  blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+int pack_weights_multi_impl(const float* src, void* dst, const stmi_pack_desc* descs, int n, int dtype, hipStream_t s) {
+    for (int first = 0; first < n; first += kMaxPackBatch) {
+        const int cnt = n - first < kMaxPackBatch ? n - first : kMaxPackBatch;
+        PackBatch b;
+        memset(&b, 0, sizeof(b));
+        for (int i = 0; i < cnt; i++) {
+            const stmi_pack_desc& d = descs[first + i];
+            b.e[i].src_off = d.src_off; b.e[i].dst_off = d.dst_off;
+            b.e[i].kh = d.kh; b.e[i].kw = d.kw; b.e[i].ci = d.ci; b.e[i].co = d.co; b.e[i].mode = d.mode;
+            b.e[i].g = pack_geom(d.kh, d.kw, d.ci, d.co, d.mode);
+        }
+        if (dtype == STMI_BF16)
+            hipLaunchKernelGGL(pack_weights_multi_kernel<bf16_t>, dim3(48, cnt), dim3(256), 0, s, src, (bf16_t*)dst, b);
+        else
+            hipLaunchKernelGGL(pack_weights_multi_kernel<float>, dim3(48, cnt), dim3(256), 0, s, src, (float*)dst, b);
+        STMI_LAUNCH_CHECK("pack_weights_multi_kernel");
+    }
+    return STMI_OK;
 }
 
 // Builds the tap table of a forward convolution (gathers x, writes y).

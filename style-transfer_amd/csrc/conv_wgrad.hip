@@ -226,6 +226,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// The accumulators are cleared by a kernel of this library rather than a memset node: under
+// HIP-graph replay small hipMemsetAsync nodes ahead of the atomic adds were observed to leave
+// stale values in the first replays' smallest buffers.
+__global__ void zero_f32_kernel(float* p, long count) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+static int zero_f32(float* p, long count, hipStream_t s) {
+    long blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, count);
+    STMI_LAUNCH_CHECK("zero_f32_kernel");
+    return STMI_OK;
+}
+
 template <typename T, int TR, int TCN, int WR, int WCN>
 static int launch_wg(WgradParams& p, hipStream_t s) {
     constexpr int BLK_R = 16 * TR * WR, BLK_C = 16 * TCN * WCN;
@@ -270,9 +285,9 @@ static int launch_wg_typed(WgradParams& p, hipStream_t s) {
     return launch_wg<T, 1, 1, 2, 2>(p, s);                                // 32 x 32
 }
 
-// dw (fp32, zeroed here) [kh,kw,ci,co] of conv(n,h,w,ci -> co, k, stride)
+// dw (fp32; zeroed here unless accumulate) [kh,kw,ci,co] of conv(n,h,w,ci -> co, k, stride)
 int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
-                    int stride, int dtype, hipStream_t s) {
+                    int stride, int accumulate, int dtype, hipStream_t s) {
     int ho, wo, pt, pl;
     same_pads(h, kh, stride, &ho, &pt);
     same_pads(w, kw, stride, &wo, &pl);
@@ -298,8 +313,10 @@ int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int 
         }
         p.taps[t].widx = t;
     }
-    int rc = check_hip(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)kh * kw * ci * co, s), "memset dw");
-    if (rc) return rc;
+    if (!accumulate) {
+        int rc = zero_f32(dw, (long)kh * kw * ci * co, s);
+        if (rc) return rc;
+    }
     if (dtype == STMI_BF16) return launch_wg_typed<bf16_t>(p, s);
     return launch_wg_typed<float>(p, s);
 }
@@ -317,7 +334,7 @@ int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype
     p.ntaps = 1; p.klen = c; p.cdiv = 0;
     p.tap_out_stride = 0;
     p.batch_out_stride = (long)c * c;
-    int rc = check_hip(hipMemsetAsync(g, 0, sizeof(float) * (size_t)n * c * c, s), "memset gram");
+    int rc = zero_f32(g, (long)n * c * c, s);
     if (rc) return rc;
     if (dtype == STMI_BF16) return launch_wg_typed<bf16_t>(p, s);
     return launch_wg_typed<float>(p, s);

@@ -85,19 +85,35 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
     block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, g.C, CG, slots, active);
 }
 
-// stats[n][c] = (mean, 1/sqrt(var + eps)) from the shifted partial sums
-template <typename T>
-__global__ __launch_bounds__(256) void in_stats_finalize_kernel(const T* __restrict__ x, const float* __restrict__ ws,
-                                                                float* __restrict__ stats, float eps, InGeom g) {
-    const int n = blockIdx.x;
-    const float inv = 1.f / (float)g.HW;
-    for (int c = threadIdx.x; c < g.C; c += 256) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int s = 0; s < g.S; s++) {
+// Finalize kernels: grid (N, ceil(C/8)); 32 lanes cooperate on one channel's S partials.
+__device__ __forceinline__ void fold_partials(const float* __restrict__ ws, const InGeom& g, int n, int c, float& s1,
+                                              float& s2) {
+    const int l32 = threadIdx.x & 31;
+    s1 = 0.f;
+    s2 = 0.f;
+    if (c < g.C) {
+        for (int s = l32; s < g.S; s += 32) {
             const float* w = ws + ((long)n * g.S + s) * 2 * g.C;
             s1 += w[c];
             s2 += w[g.C + c];
         }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+}
+
+// stats[n][c] = (mean, 1/sqrt(var + eps)) from the shifted partial sums
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_finalize_kernel(const T* __restrict__ x, const float* __restrict__ ws,
+                                                                float* __restrict__ stats, float eps, InGeom g) {
+    const int n = blockIdx.x, c = blockIdx.y * 8 + (threadIdx.x >> 5);
+    float s1, s2;
+    fold_partials(ws, g, n, c, s1, s2);
+    if (c < g.C && (threadIdx.x & 31) == 0) {
+        const float inv = 1.f / (float)g.HW;
         const float k = to_f32<T>(x[(long)n * g.HW * g.C + c]);
         const float m = s1 * inv;
         const float var = fmaxf(s2 * inv - m * m, 0.f);
@@ -189,15 +205,11 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
 // backward pass 2: means[n][c] = (mean(g), mean(g*xhat)); parameter gradients summed over samples
 __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ means,
                                                               float* dscale, float* dshift, InGeom g) {
-    const int n = blockIdx.x;
-    const float inv = 1.f / (float)g.HW;
-    for (int c = threadIdx.x; c < g.C; c += 256) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int s = 0; s < g.S; s++) {
-            const float* w = ws + ((long)n * g.S + s) * 2 * g.C;
-            s1 += w[c];
-            s2 += w[g.C + c];
-        }
+    const int n = blockIdx.x, c = blockIdx.y * 8 + (threadIdx.x >> 5);
+    float s1, s2;
+    fold_partials(ws, g, n, c, s1, s2);
+    if (c < g.C && (threadIdx.x & 31) == 0) {
+        const float inv = 1.f / (float)g.HW;
         atomicAdd(dshift + c, s1);
         atomicAdd(dscale + c, s2);
         means[((long)n * g.C + c) * 2] = s1 * inv;
@@ -294,7 +306,7 @@ static int stats_typed(const void* x, float* ws, float* stats, float eps, int n,
         hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, ws, g);
     });
-    hipLaunchKernelGGL((in_stats_finalize_kernel<T>), dim3(n), dim3(256), 0, s, (const T*)x, ws, stats, eps, g);
+    hipLaunchKernelGGL((in_stats_finalize_kernel<T>), dim3(n, (c + 7) / 8), dim3(256), 0, s, (const T*)x, ws, stats, eps, g);
     STMI_LAUNCH_CHECK("in_stats kernels");
     return STMI_OK;
 }
@@ -323,7 +335,7 @@ static int bwd_typed(const void* x, const void* dy, const float* stats, const fl
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, (const T*)dy, stats, scale, shift, ws, act, g);
-        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(n), dim3(256), 0, s, (const float*)ws, means, dscale, dshift, g);
+        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(n, (c + 7) / 8), dim3(256), 0, s, (const float*)ws, means, dscale, dshift, g);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x,
                            (const T*)dy, stats, scale, shift, (const float*)means, (T*)dx, act, g);
     });

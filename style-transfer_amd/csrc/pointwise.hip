@@ -180,6 +180,14 @@ int pool_bwd_impl(const void* x, const void* dy, void* dx, int n, int h, int w, 
 }
 
 // --------------------------------------------------------------------- losses
+// The loss kernels end in one atomic add per block on a single address: keep the grid small.
+static inline int reduce_blocks(long work_items) {
+    long b = (work_items + 2047) / 2048;
+    if (b > 128) b = 128;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
 // loss[0] += loss_scale * sum((a-b)^2); grad = grad_scale * (a-b)
 template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ grad,
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const
 
 int mse_impl(const void* a, const void* b, void* grad, float* loss, float loss_scale, float grad_scale, long count,
              int dtype, hipStream_t s) {
-    const dim3 grid(flat_blocks((count + 3) / 4));
+    const dim3 grid(reduce_blocks(count));
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(mse_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)grad, loss, loss_scale, grad_scale, count);
     else
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
 int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, float loss_scale, float grad_scale,
                   int n, int c, int dtype, hipStream_t s) {
     const int rows_pad = packed_rows(c), kpad = round_up(c, 32);
-    const dim3 grid(flat_blocks((long)n * rows_pad * kpad));
+    const dim3 grid(reduce_blocks((long)n * rows_pad * kpad));
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(gram_mse_kernel<bf16_t>, grid, dim3(256), 0, s, g, target, (bf16_t*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
     else
@@ -276,7 +284,7 @@ int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int 
     // reduce_mean over [n,h,w-1,c] and [n,h-1,w,c]; a 1-wide axis gives an empty mean (NaN in TF): treated as 0 here
     const float wx = w > 1 ? weight / ((float)n * h * (w - 1) * c) : 0.f;
     const float wy = h > 1 ? weight / ((float)n * (h - 1) * w * c) : 0.f;
-    const dim3 grid(flat_blocks((long)n * h * w * c));
+    const dim3 grid(reduce_blocks((long)n * h * w * c));
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, n, h, w, c);
     else

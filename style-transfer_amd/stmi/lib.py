@@ -25,12 +25,13 @@ SIGNATURES = {
     'stmi_conv_kernel_name': (_c_int, [_c_int, _c_long, _c_int, _c_int, ctypes.c_char_p, _c_int]),
     'stmi_conv_packed_elems': (_c_long, [_c_int] * 5),
     'stmi_pack_conv_weights': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp]),
+    'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float] + _CONV + [_c_int, _vp]),
-    'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
+    'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_fwd': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_dgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
-    'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
+    'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_instance_norm_ws_floats': (_c_long, [_c_int] * 4),
     'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
@@ -52,6 +53,14 @@ SIGNATURES = {
     'stmi_activation': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_clip': (_c_int, [_vp, _c_long, _c_float, _c_float, _vp]),
 }
+
+
+
+class PackDesc(ctypes.Structure):
+    """stmi_pack_desc of include/stmi.h"""
+    _fields_ = [('src_off', _c_long), ('dst_off', _c_long), ('kh', _c_int), ('kw', _c_int), ('ci', _c_int),
+                ('co', _c_int), ('mode', _c_int), ('reserved', _c_int)]
+
 
 _lib = None
 

@@ -93,6 +93,23 @@ def pack_conv_weights(w_hwio, mode, dtype, out=None):
     return out
 
 
+def make_pack_table(entries):
+    """entries: iterable of (src_off, dst_off, (kh, kw, ci, co), mode) -> ctypes table for pack_conv_weights_multi."""
+    entries = list(entries)
+    table = (_lib.PackDesc * len(entries))()
+    for d, (src, dst, (kh, kw, ci, co), mode) in zip(table, entries):
+        d.src_off, d.dst_off, d.kh, d.kw, d.ci, d.co, d.mode = src, dst, kh, kw, ci, co, mode
+    return table
+
+
+def pack_conv_weights_multi(src_flat, dst_flat, table):
+    """All tensors of `table` in one launch: fp32 flat buffer -> packed flat buffer."""
+    _chk(src_flat, 'src_flat', torch.float32)
+    _chk(dst_flat, 'dst_flat')
+    _lib.call('stmi_pack_conv_weights_multi', src_flat.data_ptr(), dst_flat.data_ptr(), table, len(table),
+              _dt(dst_flat), _stream())
+
+
 # ------------------------------------------------------------------- conv
 def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=False, out=None, out_pre=None):
     """kshape = (kh, kw, ci, co) of the HWIO weight that was packed with PACK_FWD."""
@@ -132,7 +149,7 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
     return dx
 
 
-def conv2d_wgrad(x, dy, kshape, stride, out=None):
+def conv2d_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
     kh, kw, ci, co = kshape
     n, h, w, c = x.shape
     assert c == ci
@@ -140,7 +157,7 @@ def conv2d_wgrad(x, dy, kshape, stride, out=None):
     _chk(dy, 'dy', x.dtype, (n, same_out(h, stride), same_out(w, stride), co))
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
     _lib.call('stmi_conv2d_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co, kh, kw, stride,
-              _dt(x), _stream())
+              int(accumulate), _dt(x), _stream())
     return dw
 
 
@@ -175,7 +192,7 @@ def conv2d_transpose_dgrad(dy, w_packed, kshape, stride, addend=None, out=None):
     return dx
 
 
-def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None):
+def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
     kh, kw, co, ci = kshape
     n, h, w, c = x.shape
     assert c == ci
@@ -183,7 +200,7 @@ def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None):
     _chk(dy, 'dy', x.dtype, (n, h * stride, w * stride, co))
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
     _lib.call('stmi_conv2d_transpose_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co,
-              kh, kw, stride, _dt(x), _stream())
+              kh, kw, stride, int(accumulate), _dt(x), _stream())
     return dw
 
 

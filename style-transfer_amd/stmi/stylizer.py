@@ -109,9 +109,9 @@ class StylizerNet:
                     b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
             b.fwd_mode, b.bwd_mode = fwd_mode, bwd_mode
             b.W, b.shift, b.scale = self.views[3 * i], self.views[3 * i + 1], self.views[3 * i + 2]
-            b.wp_fwd = torch.empty(ops.packed_elems(*pk, fwd_mode), dtype=dtype, device=device)
-            b.wp_bwd = (torch.empty(ops.packed_elems(*pk, bwd_mode), dtype=dtype, device=device)
-                        if training and i > 0 else None)
+            b.pk = pk
+            b.n_fwd = ops.packed_elems(*pk, fwd_mode)
+            b.n_bwd = ops.packed_elems(*pk, bwd_mode) if training and i > 0 else 0
             oshape = (batch, b.out_h, b.out_w, co)
             b.stats = torch.empty((batch, co, 2), dtype=torch.float32, device=device)
             if training:
@@ -122,6 +122,19 @@ class StylizerNet:
             ws_floats = max(ws_floats, ops._lib.load().stmi_instance_norm_ws_floats(batch, b.out_h, b.out_w, co))
             self.blocks.append(b)
             h, w, c = b.out_h, b.out_w, co
+        # all packed weight copies live in one buffer so that one launch refreshes them
+        total, table = 0, []
+        for i, b in enumerate(self.blocks):
+            b.off_fwd, total = total, total + (b.n_fwd + 63) // 64 * 64
+            table.append((int(offs[3 * i]), b.off_fwd, b.pk, b.fwd_mode))
+            if b.n_bwd:
+                b.off_bwd, total = total, total + (b.n_bwd + 63) // 64 * 64
+                table.append((int(offs[3 * i]), b.off_bwd, b.pk, b.bwd_mode))
+        self.packed = torch.zeros(total, dtype=dtype, device=device)
+        self._pack_table = ops.make_pack_table(table)
+        for b in self.blocks:
+            b.wp_fwd = self.packed[b.off_fwd:b.off_fwd + b.n_fwd]
+            b.wp_bwd = self.packed[b.off_bwd:b.off_bwd + b.n_bwd] if b.n_bwd else None
         self.out_f32 = torch.empty((batch, h, w, 3), dtype=torch.float32, device=device)
         self.ws = torch.empty(ws_floats, dtype=torch.float32, device=device)
         if not training:
@@ -146,10 +159,7 @@ class StylizerNet:
 
     def repack(self):
         """Refreshes the K-contiguous weight copies after the fp32 masters changed."""
-        for b in self.blocks:
-            ops.pack_conv_weights(b.W, b.fwd_mode, self.dtype, out=b.wp_fwd)
-            if b.wp_bwd is not None:
-                ops.pack_conv_weights(b.W, b.bwd_mode, self.dtype, out=b.wp_bwd)
+        ops.pack_conv_weights_multi(self.flat, self.packed, self._pack_table)
 
     # --------------------------------------------------------------- forward
     def _view(self, buf, b):
@@ -219,7 +229,7 @@ class StylizerNet:
                                   ws=self.ws, out=dconv)
             rows_g = None
             if b.kind == 'deconv':
-                ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
+                ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
             elif b.rows == 'in':      # rows_buf still holds the forward's input patches
                 ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
                 ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
@@ -228,7 +238,7 @@ class StylizerNet:
                 ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
                 ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             else:
-                ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW)
+                ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
             if i == 0:
                 break
             n_in = self.n * b.in_h * b.in_w * b.ci

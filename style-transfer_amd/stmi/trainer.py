@@ -87,7 +87,7 @@ class StyleTrainer:
     def _front(self):
         self.losses.zero_()
         self.net.flat_grad.zero_()
-        _, content_target = self.rep_content.forward(self.batch_in)
+        _, content_target = self.rep_content.forward(self.batch_in, want_grams=False)
         out = self.net.forward(self.batch_in)
         d_out = self.rep_loss.loss_and_grad(out, self.style_targets, content_target,
                                             self.sw, self.cw, self.tvw, self.losses)

@@ -107,8 +107,9 @@ class VggReplica:
         raise RuntimeError('no free scratch buffer')
 
     # --------------------------------------------------------------- forward
-    def forward(self, x_f32):
+    def forward(self, x_f32, want_grams=True):
         """Fills self.grams (5 x fp32 [n,c,c]) and self.content from an fp32 image batch in [0,1]."""
+        self._want_grams = want_grams
         net = self.net
         ops.scale_shift(x_f32, net.mean, 255.0 / 2.0, net.dtype, out=self.x_pre)
         cur = self.x_pre
@@ -120,7 +121,7 @@ class VggReplica:
             if name.startswith('conv'):
                 L = net.convs[name]
                 has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
-                tap_pre = (not self.relu_taps) and (name in STYLE_CONV_TAPS or name == CONTENT_CONV_TAP)
+                tap_pre = (not self.relu_taps) and want_grams and name in STYLE_CONV_TAPS
                 if has_relu:
                     rname = names[i + 1]
                     if self.keep:
@@ -153,7 +154,7 @@ class VggReplica:
     def _tap(self, name, tensor):
         if tensor is None:
             return
-        if name in self.style_names:
+        if name in self.style_names and self._want_grams:
             ops.gram_fwd(tensor, out=self.grams[self.style_names.index(name)])
         if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
             self.content.copy_(tensor)
