@@ -9,7 +9,10 @@
 //     from chunk p ^ ((r>>1)&7), and fragment reads apply the same XOR, which makes the
 //     16-row x 4-chunk ds_read_b128 pattern conflict-free on 128-byte rows;
 //   * rows that fall outside the image are fetched from a 128-byte page of zeros.
-// Two LDS buffers; the DMA for step s+1 is in flight while step s is multiplied.
+// The K loop is an NS-deep ring of LDS buffers.  At these problem sizes a CU holds one or
+// two blocks, so throughput is (bytes in flight) / (DMA latency): NS-1 steps stay in flight
+// behind a COUNTED s_waitcnt vmcnt and one raw s_barrier per step (a __syncthreads() would
+// drain the ring with vmcnt(0)).
 #include "conv_gemm.hpp"
 
 #include <stdlib.h>
@@ -24,17 +27,44 @@ __device__ __forceinline__ void glds16(const T* src, uint4* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, int TC, int TP, int WC, int WP>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ds_read_b128 the compiler does not see as an LDS access; the value is valid only after
+// lds_wait() followed by lds_landed() on the same register.
+__device__ __forceinline__ u32x4 lds_read16(unsigned addr, int imm) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_landed(u32x4& v) { asm volatile("" : "+v"(v)); }
+
+// all waves' DMA for the step has landed (each waited on its own counter) and every wave
+// is done reading the buffer that is refilled next
+__device__ __forceinline__ void ring_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename T, int TC, int TP, int WC, int WP, int NS>
 __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvGemmParams p) {
     static_assert(WC * WP == 4, "4 waves per block");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;  // K elements per step: 128 bytes per row
     constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
     constexpr int NI_W = BLK_CO / 32, NI_P = BLK_PIX / 32;  // DMA instructions per wave and step
+    constexpr int NI = NI_W + NI_P;
+    constexpr int STAGE = (BLK_CO + BLK_PIX) * 8;  // uint4 per ring slot
     static_assert(BLK_CO % 32 == 0 && BLK_PIX % 32 == 0, "tile rows must split into 8-row DMA pieces over 4 waves");
     typedef typename Mma<T>::frag frag;
 
-    __shared__ uint4 lds[2][(BLK_CO + BLK_PIX) * 8];
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WP, wpx = wave % WP;
@@ -85,57 +115,87 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvGemmParam
 #pragma unroll
         for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int buf, int t, int k0) {
-        const Tap tap = p.taps[t];
+    const int ksteps = p.klen / BK;
+    const int nsteps = p.ntaps * ksteps;
+    int st_t = 0, st_k = 0;  // (tap, k-chunk) of the next step to stage
+
+    auto stage_next = [&](int slot) {
+        uint4* buf = lds + slot * STAGE;
+        const Tap tap = p.taps[st_t];
+        const int k0 = st_k * BK;
         const T* wsrc = wp + ((long)tap.widx * p.co_pad + co0) * p.kpad + k0;
 #pragma unroll
-        for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], &lds[buf][(wave * NI_W + j) * 64]);
+        for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], buf + (wave * NI_W + j) * 64);
         const long tdelta = ((long)tap.dy * p.Wi + tap.dx) * p.Ci + k0;
 #pragma unroll
         for (int j = 0; j < NI_P; j++) {
             const int iy = py[j] + tap.dy, ix = px[j] + tap.dx;
             const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            glds16(ok ? in + pbase[j] + tdelta : zero_src, &lds[buf][(BLK_CO / 8 + wave * NI_P + j) * 64]);
+            glds16(ok ? in + pbase[j] + tdelta : zero_src, buf + (BLK_CO / 8 + wave * NI_P + j) * 64);
         }
+        if (++st_k == ksteps) { st_k = 0; ++st_t; }
     };
 
-    auto compute = [&](int buf) {
+    // Fragment reads go through inline asm: a compiler-visible LDS load after an LDS-DMA
+    // write that it cannot prove disjoint is preceded by s_waitcnt vmcnt(0), which would
+    // drain the ring every step.  Only lgkmcnt(0) waits are used (scalar loads share the
+    // counter and return out of order).
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const unsigned frag_off = r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);  // kk = 1 flips chunk bit 2
+    const unsigned a_addr0 = lds_base + wc * TC * 2048 + frag_off;
+    const unsigned a_addr1 = lds_base + wc * TC * 2048 + (frag_off ^ 64);
+    const unsigned b_addr0 = lds_base + BLK_CO * 128 + wpx * TP * 2048 + frag_off;
+    const unsigned b_addr1 = lds_base + BLK_CO * 128 + wpx * TP * 2048 + (frag_off ^ 64);
+
+    auto compute = [&](int slot) {
+        const unsigned so = slot * (STAGE * 16);
+        u32x4 a0[TC], b0[TP], a1[TC], b1[TP];
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            frag a[TC], b[TP];
+        for (int tc = 0; tc < TC; tc++) a0[tc] = lds_read16(a_addr0 + so, tc * 2048);
 #pragma unroll
-            for (int tc = 0; tc < TC; tc++) {
-                const int row = (wc * TC + tc) * 16 + r16;
-                const uint4 raw = lds[buf][row * 8 + ((4 * kk + g) ^ ((row >> 1) & 7))];
-                a[tc] = *reinterpret_cast<const frag*>(&raw);
-            }
+        for (int tp = 0; tp < TP; tp++) b0[tp] = lds_read16(b_addr0 + so, tp * 2048);
+        lds_wait();
 #pragma unroll
-            for (int tp = 0; tp < TP; tp++) {
-                const int row = (wpx * TP + tp) * 16 + r16;
-                const uint4 raw = lds[buf][(BLK_CO + row) * 8 + ((4 * kk + g) ^ ((row >> 1) & 7))];
-                b[tp] = *reinterpret_cast<const frag*>(&raw);
-            }
+        for (int tc = 0; tc < TC; tc++) lds_landed(a0[tc]);
 #pragma unroll
-            for (int tc = 0; tc < TC; tc++)
+        for (int tp = 0; tp < TP; tp++) lds_landed(b0[tp]);
 #pragma unroll
-                for (int tp = 0; tp < TP; tp++) Mma<T>::mma(a[tc], b[tp], acc[tc][tp]);
-        }
+        for (int tc = 0; tc < TC; tc++) a1[tc] = lds_read16(a_addr1 + so, tc * 2048);
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) b1[tp] = lds_read16(b_addr1 + so, tp * 2048);
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++)
+                Mma<T>::mma(__builtin_bit_cast(frag, a0[tc]), __builtin_bit_cast(frag, b0[tp]), acc[tc][tp]);
+        lds_wait();
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++) lds_landed(a1[tc]);
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) lds_landed(b1[tp]);
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++)
+                Mma<T>::mma(__builtin_bit_cast(frag, a1[tc]), __builtin_bit_cast(frag, b1[tp]), acc[tc][tp]);
     };
 
-    const int ksteps = p.klen / BK;
-    const int nsteps = p.ntaps * ksteps;
     if (nsteps > 0) {
-        int t = 0, ks = 0;
-        stage(0, 0, 0);
-        __syncthreads();  // drains the DMA (vmcnt) before the barrier
+        // prologue: NS-1 steps in flight
+#pragma unroll
+        for (int s = 0; s < NS - 1; s++)
+            if (s < nsteps) stage_next(s);
+        int slot = 0;
         for (int s = 0; s < nsteps; s++) {
-            const bool more = s + 1 < nsteps;
-            if (more) {
-                if (++ks == ksteps) { ks = 0; ++t; }
-                stage((s + 1) & 1, t, ks * BK);
-            }
-            compute(s & 1);
-            __syncthreads();
+            // wait for step s: everything issued after it may stay in flight
+            const int later = nsteps - 1 - s;  // steps issued after s so far: min(later, NS-2)
+            if (NS >= 4 && later >= 2) wait_vmcnt<2 * NI>();
+            else if (NS >= 3 && later >= 1) wait_vmcnt<NI>();
+            else wait_vmcnt<0>();
+            ring_barrier();
+            if (s + NS - 1 < nsteps) stage_next(slot == 0 ? NS - 1 : slot - 1);  // refill the slot step s-1 used
+            compute(slot);
+            slot = slot + 1 == NS ? 0 : slot + 1;
         }
     }
     conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wc, wpx, g, r16, Mz, zoff, HWs);
@@ -149,11 +209,11 @@ struct GldsCfg {
     const char* name;
 };
 static const GldsCfg kCfgs[] = {
-    {128, 128, "4, 4, 2, 2"},  // 0
-    {128, 64, "4, 2, 2, 2"},   // 1
-    {64, 128, "2, 4, 2, 2"},   // 2
-    {64, 64, "2, 2, 2, 2"},    // 3
-    {32, 128, "2, 2, 1, 4"},   // 4
+    {128, 128, "4, 4, 2, 2, 3"},  // 0
+    {128, 64, "4, 2, 2, 2, 3"},   // 1
+    {64, 128, "2, 4, 2, 2, 3"},   // 2
+    {64, 64, "2, 2, 2, 2, 4"},    // 3
+    {32, 128, "2, 2, 1, 4, 3"},   // 4
 };
 
 static long tiles_of(const ConvGemmParams& p, int c) {
@@ -183,14 +243,23 @@ static int pick(const ConvGemmParams& p) {
     return 3;
 }
 
-template <typename T, int TC, int TP, int WC, int WP>
+template <typename T, int TC, int TP, int WC, int WP, int NS>
 static int launch_one(const ConvGemmParams& p, hipStream_t s) {
     constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
+    constexpr size_t kLds = (size_t)NS * (BLK_CO + BLK_PIX) * 128;
+    static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; a racing second call is harmless
+    if (!attr_set) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
+                           "hipFuncSetAttribute(conv_gemm_glds_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
     if (Mz <= 0) return STMI_OK;
     dim3 grid((unsigned)ceil_div(Mz, BLK_PIX), (unsigned)(p.co_pad / BLK_CO), (unsigned)(batched ? p.N : 1));
-    hipLaunchKernelGGL((conv_gemm_glds_kernel<T, TC, TP, WC, WP>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>), grid, dim3(256), kLds, s, p);
     STMI_LAUNCH_CHECK("conv_gemm_glds_kernel");
     return STMI_OK;
 }
@@ -198,11 +267,11 @@ static int launch_one(const ConvGemmParams& p, hipStream_t s) {
 template <typename T>
 static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
     switch (pick(p)) {
-        case 0: return launch_one<T, 4, 4, 2, 2>(p, s);
-        case 1: return launch_one<T, 4, 2, 2, 2>(p, s);
-        case 2: return launch_one<T, 2, 4, 2, 2>(p, s);
-        case 3: return launch_one<T, 2, 2, 2, 2>(p, s);
-        default: return launch_one<T, 2, 2, 1, 4>(p, s);
+        case 0: return launch_one<T, 4, 4, 2, 2, 3>(p, s);
+        case 1: return launch_one<T, 4, 2, 2, 2, 3>(p, s);
+        case 2: return launch_one<T, 2, 4, 2, 2, 3>(p, s);
+        case 3: return launch_one<T, 2, 2, 2, 2, 4>(p, s);
+        default: return launch_one<T, 2, 2, 1, 4, 3>(p, s);
     }
 }
 
