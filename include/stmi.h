@@ -50,10 +50,9 @@ const char* stmi_last_error(void);
 /* writes e.g. "gfx950:sramecc+:xnack-" of the current device */
 int stmi_device_arch(char* buf, int buflen);
 
-/* Profiling aid: the name a profiler shows for the kernel instantiation that a stride-1
- * convolution (forward or backward-data) writing `out_channels` x `out_pixels` and reducing
- * over `k_channels` channels per tap launches. */
-int stmi_conv_kernel_name(int out_channels, long out_pixels, int k_channels, int dtype, char* buf, int buflen);
+/* Profiling aid: the name a profiler shows for the kernel instantiation that this thread's
+ * most recent convolution forward / backward-data call launched (empty before the first). */
+int stmi_last_conv_kernel(char* buf, int buflen);
 
 /* ---- weight packing ---------------------------------------------------- */
 /* Weights live as fp32 HWIO [kh,kw,ci,co] (the layout of the reference's

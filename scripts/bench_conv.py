@@ -1,5 +1,5 @@
 """Per-layer timing of the conv gather-GEMM kernels on the heavy layer shapes of the
-training step (batch 4, 256x256).  STMI_CONV_CFG / STMI_NO_GLDS select the variant."""
+training step (batch 4, 256x256).  STMI_CONV_CFG / STMI_NO_GLDS / STMI_NO_PATCH / STMI_PATCH_CO select the variant."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,18 +14,29 @@ LAYERS = [  # name, h, w, ci, co
     ('vgg3_1', 64, 64, 128, 256), ('vgg3_x', 64, 64, 256, 256), ('vgg4_1', 32, 32, 256, 512),
     ('vgg4_x', 32, 32, 512, 512), ('vgg5_x', 16, 16, 512, 512), ('res', 64, 64, 128, 128),
 ]
-cfgs = [None, 'v1', '0', '1', '2', '3']
+cfgs = [None, 'v1', '0', '1', '2', '3', 'p64', 'p128']
 
 def run(x, wp, kshape, y, iters=20):
-    for _ in range(3):
-        ops.conv2d_fwd(x, wp, kshape, 1, out=y)
+    """us per launch, launches replayed from a HIP graph so that host launch cost is not measured"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ops.conv2d_fwd(x, wp, kshape, 1, out=y)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            ops.conv2d_fwd(x, wp, kshape, 1, out=y)
+    graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        ops.conv2d_fwd(x, wp, kshape, 1, out=y)
+    for _ in range(5):
+        graph.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / (5 * iters) * 1e3
 
 print('%-8s %10s | ' % ('layer', 'GFLOP') + ' '.join('%9s' % (c or 'auto') for c in cfgs) + '   (TFLOP/s)')
 for name, h, w, ci, co in LAYERS:
@@ -36,13 +47,14 @@ for name, h, w, ci, co in LAYERS:
     flops = 2.0 * B * h * w * co * 9 * ci
     row, ref = [], None
     for c in cfgs:
-        os.environ.pop('STMI_CONV_CFG', None); os.environ.pop('STMI_NO_GLDS', None)
-        if c == 'v1': os.environ['STMI_NO_GLDS'] = '1'
-        elif c is not None: os.environ['STMI_CONV_CFG'] = c
+        for k in ('STMI_CONV_CFG', 'STMI_NO_GLDS', 'STMI_NO_PATCH', 'STMI_PATCH_CO'): os.environ.pop(k, None)
+        if c == 'v1': os.environ['STMI_NO_GLDS'] = '1'; os.environ['STMI_NO_PATCH'] = '1'
+        elif c in ('p64', 'p128'): os.environ['STMI_PATCH_CO'] = c[1:]
+        elif c is not None: os.environ['STMI_CONV_CFG'] = c; os.environ['STMI_NO_PATCH'] = '1'
         t = run(x, wp, (3, 3, ci, co), y)
         if c == 'v1': ref = y.float().clone()
         elif ref is not None:
             err = ((y.float() - ref).abs().max() / ref.abs().max()).item()
             assert err < 2e-2, (name, c, err)
-        row.append(flops / t / 1e12)
+        row.append(flops / (t * 1e-6) / 1e12)
     print('%-8s %10.2f | ' % (name, flops / 1e9) + ' '.join('%9.1f' % v for v in row))

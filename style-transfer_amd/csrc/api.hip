@@ -21,7 +21,7 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 // implemented in the kernel translation units
-void conv_kernel_name(int rows, long pixels, int kchannels, int dtype, char* buf, int buflen);
+const char* last_conv_kernel();
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int pack_weights_multi_impl(const float*, void*, const stmi_pack_desc*, int, int, hipStream_t);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
@@ -92,10 +92,9 @@ int stmi_device_arch(char* buf, int buflen) {
     return STMI_OK;
 }
 
-int stmi_conv_kernel_name(int out_channels, long out_pixels, int k_channels, int dtype, char* buf, int buflen) {
-    if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(buf && buflen > 0 && out_channels > 0 && out_pixels > 0 && k_channels > 0, "conv_kernel_name: bad arguments");
-    conv_kernel_name(out_channels, out_pixels, k_channels, dtype, buf, buflen);
+int stmi_last_conv_kernel(char* buf, int buflen) {
+    STMI_REQUIRE(buf && buflen > 0, "last_conv_kernel: bad arguments");
+    snprintf(buf, buflen, "%s", last_conv_kernel());
     return STMI_OK;
 }
 

@@ -214,30 +214,37 @@ static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
     }
 }
 
-int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t s) {
+static thread_local char g_last_conv_kernel[192] = "";
+static const char* kV1Cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
+
+// Kernel choice: LDS-resident patch kernel for 3x3 stride-1 layers, LDS-DMA gather-GEMM for
+// the other layers with >= 128 bytes of K per tap, register-staged gather-GEMM for the rest.
+// The name of the instantiation launched is kept per thread for profiling front ends.
+int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     int rc = STMI_OK;
-    if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) return rc;
+    const char* tname = dtype == STMI_BF16 ? "__bf16" : "float";
+    ConvGemmParams p = p_in;
+    {
+        const int epc = dtype == STMI_BF16 ? 8 : 4;
+        const uintptr_t ptrs = (uintptr_t)p.out | (uintptr_t)p.out_pre | (uintptr_t)p.mask | (uintptr_t)p.addend;
+        p.row_store_ok = p.Co % epc == 0 && (ptrs & 15) == 0;
+        p.dbg = 0;
+    }
+    if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+    if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) {
+        snprintf(g_last_conv_kernel, sizeof(g_last_conv_kernel),
+                 "void stmi::conv_gemm_glds_kernel<%s, %s>(stmi::ConvGemmParams)", tname, conv_gemm_glds_cfg_name(p, dtype));
+        return rc;
+    }
+    const bool batched = p.w_batch_stride != 0;
+    const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
+    snprintf(g_last_conv_kernel, sizeof(g_last_conv_kernel), "void stmi::conv_gemm_kernel<%s, %s>(stmi::ConvGemmParams)",
+             tname, kV1Cfg[pick_cfg(p.co_pad, Mz, batched ? p.N : 1)]);
     if (dtype == STMI_BF16) return launch_typed<bf16_t>(p, s);
     return launch_typed<float>(p, s);
 }
 
-// Name (as a profiler prints it) of the kernel instantiation a stride-1 conv forward or
-// backward-data of this geometry launches.
-void conv_kernel_name(int rows, long pixels, int kchannels, int dtype, char* buf, int buflen) {
-    static const char* cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
-    const char* tname = dtype == STMI_BF16 ? "__bf16" : "float";
-    ConvGemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.N = 1; p.Hs = 1; p.Ws = (int)pixels;
-    p.ntaps = 1; p.klen = kchannels; p.cdiv = (kchannels % 8) ? kchannels : 0;
-    p.co_pad = packed_rows(rows);
-    const char* glds = conv_gemm_glds_cfg_name(p, dtype);
-    if (glds)
-        snprintf(buf, buflen, "void stmi::conv_gemm_glds_kernel<%s, %s>(stmi::ConvGemmParams)", tname, glds);
-    else
-        snprintf(buf, buflen, "void stmi::conv_gemm_kernel<%s, %s>(stmi::ConvGemmParams)", tname,
-                 cfg[pick_cfg(p.co_pad, pixels, 1)]);
-}
+const char* last_conv_kernel() { return g_last_conv_kernel; }
 
 // rows of a packed weight set are padded so that every block tile height divides them
 int packed_rows(int rows) {

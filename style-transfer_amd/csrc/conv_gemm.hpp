@@ -20,56 +20,61 @@ struct ConvGemmParams {
     long w_batch_stride;  // != 0: one weight set per sample (Gram backward)
     float alpha;
     int relu;
+    int row_store_ok;  // Co and the tensors' alignment allow whole-row 16-byte stores (set by the launcher)
+    int dbg;  // tuning aid of the patch kernel: bit 0 skips the fills, bit 1 the LDS reads and MFMAs
     Tap taps[kMaxTaps];
 };
 
 // Epilogue shared by the kernels.  Accumulator tile (tc, tp) of a wave holds, in lane
-// (g = lane>>4, r16 = lane&15), channels co..co+3 (co = co0 + (wc*TC+tc)*16 + 4g) of pixel
-// column pix0 + (wpx*TP+tp)*16 + r16:   v = (acc + bias) * alpha ; masked ; + addend ;
-// optional pre-ReLU copy ; optional ReLU ; store.
-template <typename T, int TC, int TP>
-__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0, long pix0,
-                                              int wc, int wpx, int g, int r16, long Mz, long zoff, int HWs) {
-    T* out = (T*)p.out;
-    T* out_pre = (T*)p.out_pre;
-    const T* mask = (const T*)p.mask;
-    const T* addend = (const T*)p.addend;
+// (g = lane>>4, r16 = lane&15), channels co..co+3 (co = co0 + (wc*TC+tc)*16 + 4g) of the
+// lane's pixel column tp;  pixel_offset(tp) gives the element offset of that pixel in the
+// written tensor, or a negative value when the column is outside it:
+//   v = (acc + bias) * alpha ; masked ; + addend ; optional pre-ReLU copy ; optional ReLU ; store.
+template <typename T, int TC, int TP, typename PixelOffset>
+__device__ __forceinline__ void conv_epilogue_at(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0, int wc,
+                                                 int g, PixelOffset pixel_offset) {
+    T* __restrict__ out = (T*)p.out;
+    T* __restrict__ out_pre = (T*)p.out_pre;
+    const T* __restrict__ mask = (const T*)p.mask;
+    const T* __restrict__ addend = (const T*)p.addend;
+    const float* __restrict__ bias = p.bias;
     const bool vec_ok = (p.Co & 3) == 0;
+    // Loads first, stores last: a load issued between two stores waits for its data with
+    // the stores still queued behind it, and sixteen such round trips cost microseconds.
+    float bias_r[TC][4];
+#pragma unroll
+    for (int tc = 0; tc < TC; tc++) {
+        const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
+#pragma unroll
+        for (int u = 0; u < 4; u++) bias_r[tc][u] = bias && co + u < p.Co ? bias[co + u] : 0.f;
+    }
 #pragma unroll
     for (int tp = 0; tp < TP; tp++) {
-        const long m = pix0 + (wpx * TP + tp) * 16 + r16;
-        if (m >= Mz) continue;
-        const long mm = m + zoff;
-        const int n = (int)(mm / HWs);
-        const int rem = (int)(mm - (long)n * HWs);
-        const int i = rem / p.Ws, j = rem - i * p.Ws;
-        const long off = (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
+        const long off = pixel_offset(tp);
+        if (off < 0) continue;
+        if (vec_ok) {
+            float mk[TC][4], ad[TC][4];
 #pragma unroll
-        for (int tc = 0; tc < TC; tc++) {
-            const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
-            if (co >= p.Co) continue;
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = acc[tc][tp][u];
-            if (p.bias) {
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (co + u < p.Co) v[u] += p.bias[co + u];
+            for (int tc = 0; tc < TC; tc++) {
+                const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
+                if (co >= p.Co) continue;
+                if (mask) load_vec<T, 4>(mask + off + co, mk[tc]);
+                if (addend) load_vec<T, 4>(addend + off + co, ad[tc]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] *= p.alpha;
-            if (vec_ok) {
-                if (mask) {
-                    float mk[4];
-                    load_vec<T, 4>(mask + off + co, mk);
+            for (int tc = 0; tc < TC; tc++) {
+                const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
+                if (co >= p.Co) continue;
+                float v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
+                for (int u = 0; u < 4; u++) v[u] = (acc[tc][tp][u] + bias_r[tc][u]) * p.alpha;
+                if (mask) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = mk[tc][u] > 0.f ? v[u] : 0.f;
                 }
                 if (addend) {
-                    float ad[4];
-                    load_vec<T, 4>(addend + off + co, ad);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] += ad[u];
+                    for (int u = 0; u < 4; u++) v[u] += ad[tc][u];
                 }
                 if (out_pre) store_vec<T, 4>(out_pre + off + co, v);
                 if (p.relu) {
@@ -77,11 +82,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, const f32
                     for (int u = 0; u < 4; u++) v[u] = fmaxf(v[u], 0.f);
                 }
                 store_vec<T, 4>(out + off + co, v);
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) {
+                const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (co + u >= p.Co) continue;
-                    float x = v[u];
+                    float x = (acc[tc][tp][u] + bias_r[tc][u]) * p.alpha;
                     if (mask) x = to_f32<T>(mask[off + co + u]) > 0.f ? x : 0.f;
                     if (addend) x += to_f32<T>(addend[off + co + u]);
                     if (out_pre) out_pre[off + co + u] = from_f32<T>(x);
@@ -93,9 +102,108 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, const f32
     }
 }
 
+// The gather-GEMM kernels number their pixel columns linearly over the output sub-grid:
+// column tp of the wave is pixel pix0 + (wpx*TP+tp)*16 + r16.
+template <typename T, int TC, int TP>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0, long pix0,
+                                              int wc, int wpx, int g, int r16, long Mz, long zoff, int HWs) {
+    conv_epilogue_at<T, TC, TP>(p, acc, co0, wc, g, [&](int tp) -> long {
+        const long m = pix0 + (wpx * TP + tp) * 16 + r16;
+        if (m >= Mz) return -1;
+        const long mm = m + zoff;
+        const int n = (int)(mm / HWs);
+        const int rem = (int)(mm - (long)n * HWs);
+        const int i = rem / p.Ws, j = rem - i * p.Ws;
+        return (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
+    });
+}
+
+// Epilogue through LDS for the kernels whose block tile is done with its LDS: the
+// accumulators' native layout gives each lane 4 channels of one pixel, i.e. 8-byte stores
+// into sixteen different pixel rows per wave-instruction, and sixteen of those per lane
+// cost about 5 us of store issue.  Staged as fp32 [pixel][channel] in LDS and read back
+// row-wise, every wave-instruction instead stores whole 128/256-byte pixel rows, 16 bytes
+// per lane.  Needs Co a multiple of the 16-byte vector and 16-byte aligned tensors
+// (p.row_store_ok); pixel_offset(local pixel) is the element offset in the written tensor
+// or negative.  All NT threads of the block must call it (waves past WC*WP only store); `stage` is BLK_PIX * (BLK_CO + 4) floats.
+template <typename T, int TC, int TP, int WC, int WP, int NT, typename PixelOffset>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
+                                                  float* stage, PixelOffset pixel_offset) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
+    constexpr int STRIDE = BLK_CO + 4;   // floats; +16 bytes keeps the 16-byte writes conflict-free
+    constexpr int LPR = BLK_CO / EPC;    // lanes per pixel row
+    constexpr int RPP = NT / LPR;        // pixel rows per pass of the block
+    static_assert(BLK_PIX % RPP == 0, "tile rows must split over the passes");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wpx = wave % WP;
+    const int g = lane >> 4, r16 = lane & 15;
+    T* __restrict__ out = (T*)p.out;
+    T* __restrict__ out_pre = (T*)p.out_pre;
+    const T* __restrict__ mask = (const T*)p.mask;
+    const T* __restrict__ addend = (const T*)p.addend;
+
+    __syncthreads();  // every wave is done reading operand tiles
+#pragma unroll
+    for (int tc = 0; tc < TC; tc++) {
+        if (wave >= WC * WP) break;  // waves beyond the MFMA grid hold no accumulators
+        const int cl = (wc * TC + tc) * 16 + 4 * g;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (co0 + cl + u < p.Co) b[u] = p.bias[co0 + cl + u];
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            const int pl = (wpx * TP + tp) * 16 + r16;
+            *reinterpret_cast<f32x4*>(stage + pl * STRIDE + cl) = (acc[tc][tp] + b) * p.alpha;
+        }
+    }
+    __syncthreads();
+    const int cl = (tid % LPR) * EPC;
+    if (co0 + cl >= p.Co) return;
+#pragma unroll
+    for (int pass = 0; pass < BLK_PIX / RPP; pass++) {
+        const int pl = pass * RPP + tid / LPR;
+        const long off = pixel_offset(pl);
+        if (off < 0) continue;
+        const long e = off + co0 + cl;
+        float v[EPC];
+#pragma unroll
+        for (int u = 0; u < EPC; u += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(stage + pl * STRIDE + cl + u);
+            v[u] = t[0]; v[u + 1] = t[1]; v[u + 2] = t[2]; v[u + 3] = t[3];
+        }
+        if (mask) {
+            float mk[EPC];
+            load_vec<T, EPC>(mask + e, mk);
+#pragma unroll
+            for (int u = 0; u < EPC; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
+        }
+        if (addend) {
+            float ad[EPC];
+            load_vec<T, EPC>(addend + e, ad);
+#pragma unroll
+            for (int u = 0; u < EPC; u++) v[u] += ad[u];
+        }
+        if (out_pre) store_vec<T, EPC>(out_pre + e, v);
+        if (p.relu) {
+#pragma unroll
+            for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
+        }
+        store_vec<T, EPC>(out + e, v);
+    }
+}
+
 // LDS-DMA variant (conv_gemm_glds.hip).  Returns true and launches when the problem fits
 // it (K per tap a multiple of 128 bytes, per-pixel validity); *rc receives the status.
 bool try_launch_conv_gemm_glds(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc);
 const char* conv_gemm_glds_cfg_name(const ConvGemmParams& p, int dtype);
+
+// 3x3 stride-1 kernel with the input patch resident in LDS (conv_patch.hip).  Returns true
+// and launches when the problem fits it; name (optional) receives the kernel's name as a
+// profiler prints it.
+bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
 }  // namespace stmi

@@ -70,12 +70,24 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvGemmParam
     const int wc = wave / WP, wpx = wave % WP;
     const int g = lane >> 4, r16 = lane & 15;
     const int sub = lane >> 3, pos = lane & 7;
-    const int co0 = blockIdx.y * BLK_CO;
-    const long pix0 = (long)blockIdx.x * BLK_PIX;
-    const int z = blockIdx.z;
     const int HWs = p.Hs * p.Ws;
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)HWs : (long)p.N * HWs;
+    // Blocks b and b+8 run on the same XCD: hand each XCD one contiguous run of tiles
+    // (channel tile fastest, then pixels, then sample), so that the pixel rows it gathers
+    // and their halos stay inside that XCD's own 4 MiB L2.
+    unsigned tile;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
+        tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    }
+    const unsigned n_co = p.co_pad / BLK_CO;
+    const unsigned n_pix = (unsigned)((Mz + BLK_PIX - 1) / BLK_PIX);
+    const int co0 = (tile % n_co) * BLK_CO;
+    const unsigned tile_p = tile / n_co;
+    const long pix0 = (long)(tile_p % n_pix) * BLK_PIX;
+    const int z = tile_p / n_pix;
     const long zoff = batched ? (long)z * HWs : 0;
     const T* in = (const T*)p.in;
     const T* wp = (const T*)p.wp + (long)z * p.w_batch_stride;
@@ -258,7 +270,9 @@ static int launch_one(const ConvGemmParams& p, hipStream_t s) {
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
     if (Mz <= 0) return STMI_OK;
-    dim3 grid((unsigned)ceil_div(Mz, BLK_PIX), (unsigned)(p.co_pad / BLK_CO), (unsigned)(batched ? p.N : 1));
+    const long tiles = (long)ceil_div(Mz, BLK_PIX) * (p.co_pad / BLK_CO) * (batched ? p.N : 1);
+    STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
+    dim3 grid((unsigned)tiles);
     hipLaunchKernelGGL((conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>), grid, dim3(256), kLds, s, p);
     STMI_LAUNCH_CHECK("conv_gemm_glds_kernel");
     return STMI_OK;

@@ -1,0 +1,394 @@
+// 3x3 stride-1 convolution with the input patch held in LDS (gfx950).
+//
+// The LDS-DMA gather-GEMM of conv_gemm_glds.hip re-fetches every pixel row once per tap, and
+// the global -> LDS path moves only about 70 GB/s per CU, so that kernel is bound by its
+// fill traffic, not by the MFMA.  Here a block owns a PH x PW rectangle of 128 output pixels
+// of one image and, per 128-byte channel chunk, keeps the (PH+2) x (PW+2) halo patch of
+// that rectangle in LDS: the nine taps read the same patch at shifted rows, and only the
+// weight tile (BLK_CO rows x 128 B) is streamed per tap.  Fill bytes per MFMA drop by
+// 2.3x (BLK_CO = 128) to 2.9x (BLK_CO = 64).
+//
+//   * weight tiles go through an NSW-deep ring, the patch is double-buffered; all fills
+//     are global_load_lds_dwordx4 (8 rows x 128 B per wave-instruction, XOR swizzle on
+//     the source side, a page of zeros behind out-of-image rows);
+//   * the nine taps of a chunk are unrolled, so the number of DMA instructions issued
+//     after the step being waited for is a compile-time constant: every step waits with
+//     a counted s_waitcnt vmcnt(N) and meets the other waves at one s_barrier;
+//   * fragment reads are inline asm (a compiler-visible LDS read after an LDS-DMA write
+//     is preceded by vmcnt(0)), software-pipelined across steps: the second K half of a
+//     step is multiplied after the barrier of the next one, under that step's first reads.
+#include "conv_gemm.hpp"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace stmi {
+
+__device__ uint4 g_patch_zero_page[8];  // zero-initialised: source of out-of-image rows
+
+__device__ long g_patch_times[4096 * 16];
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"  // host pass only: LDS pointers are 32-bit on the device
+template <typename T>
+__device__ __forceinline__ void glds16(const T* src, unsigned lds_byte_addr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_byte_addr, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ u32x4 lds_read16(unsigned addr, int imm) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_landed(u32x4& v) { asm volatile("" : "+v"(v)); }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int kPatchPieces = 9;  // 8-row DMA pieces per wave and chunk: 4 * 9 * 8 = 288 patch rows
+
+// pieces of the NEXT chunk's patch a wave issues in tap iteration t (they must land with the
+// group that carries the weights of the next chunk's first tap, NSW-1 steps ahead)
+constexpr int pieces_at(int nsw, int t) {
+    const int span = 11 - nsw;  // iterations 0 .. 10-nsw
+    const int extra = kPatchPieces - span;
+    return t < 0 || t >= span ? 0 : (t < extra ? 2 : 1);
+}
+constexpr int pieces_before(int nsw, int t) {
+    int n = 0;
+    for (int i = 0; i < t; i++) n += pieces_at(nsw, i);
+    return n;
+}
+// DMA instructions in the group issued in tap iteration t (t < 0: the previous chunk)
+constexpr int group_size(int nsw, int ni_w, bool last, int t) {
+    if (t < 0) return ni_w + pieces_at(nsw, t + 9);
+    if (last) return t + nsw - 1 <= 8 ? ni_w : 0;
+    return ni_w + pieces_at(nsw, t);
+}
+// instructions that may still be in flight when tap iteration t starts computing
+constexpr int in_flight_ok(int nsw, int ni_w, bool last, int t) {
+    int n = 0;
+    for (int j = 1; j <= nsw - 2; j++) n += group_size(nsw, ni_w, last, t - j);
+    return n;
+}
+
+}  // namespace
+
+template <typename T, int TC, int PW, int NSW>
+__global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BK = 8 * EPC;       // channels per chunk (128 bytes)
+    constexpr int TP = 4;             // 16-pixel fragments per consumer wave
+    constexpr int BLK_CO = 32 * TC;   // 2 x 2 consumer waves
+    constexpr int PH = 128 / PW;      // 128 output pixels per block
+    constexpr int FPR = PW / 16;      // fragments per patch row
+    constexpr int PWH = PW + 2;
+    constexpr int NROWS = (PH + 2) * PWH;
+    constexpr int NI_W = BLK_CO / 32;
+    constexpr int W_SLOT = BLK_CO * 128;                  // bytes
+    constexpr int P_BUF = 4 * kPatchPieces * 8 * 128;     // bytes
+    static_assert(NROWS <= 4 * kPatchPieces * 8, "patch does not fit its pieces");
+    static_assert(PW == 16 || PW == 32 || PW == 64, "patch width");
+    typedef typename Mma<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(128))) uint4 lds[];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const unsigned patch_base = lds_base + NSW * W_SLOT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long ts[5];
+    ts[0] = wall_clock64();
+    const int H = p.Hi, W = p.Wi, C = p.Ci;
+
+    // tile of this block: blocks b and b+8 share an XCD, each XCD gets one contiguous run
+    unsigned tile;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
+        tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    }
+    const unsigned n_co = p.co_pad / BLK_CO;
+    const unsigned tiles_x = (W + PW - 1) / PW, tiles_y = (H + PH - 1) / PH;
+    const int co0 = (tile % n_co) * BLK_CO;
+    unsigned tp_id = tile / n_co;
+    const int tx0 = (tp_id % tiles_x) * PW;
+    tp_id /= tiles_x;
+    const int ty0 = (tp_id % tiles_y) * PH;
+    const int n = tp_id / tiles_y;
+    const int nchunks = p.klen / BK;
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producer waves
+        // Issuing a DMA piece stalls the issuing wave for 60-180 cycles; kept out of the
+        // MFMA waves' instruction streams, that cost overlaps their work (each SIMD runs
+        // one producer and one consumer wave).
+        const int pw = wave - 4;
+        const int sub = lane >> 3, pos = lane & 7;
+        const T* in = (const T*)p.in;
+        const T* wp = (const T*)p.wp;
+        const T* zero_src = (const T*)(g_patch_zero_page + pos);
+        int wrow_off[NI_W];
+#pragma unroll
+        for (int j = 0; j < NI_W; j++) {
+            const int row = (pw * NI_W + j) * 8 + sub;
+            wrow_off[j] = row * p.kpad + (pos ^ ((row >> 1) & 7)) * EPC;
+        }
+        auto stage_weights = [&](int tap_i, int chunk, int slot) {
+            const Tap tap = p.taps[tap_i];
+            const T* wsrc = wp + ((long)tap.widx * p.co_pad + co0) * p.kpad + chunk * BK;
+            const unsigned dst = lds_base + slot * W_SLOT + pw * (NI_W * 1024);
+#pragma unroll
+            for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], dst + j * 1024);
+        };
+        // the weights of steps 0 .. NSW-2 need no per-pixel arithmetic: start them first
+#pragma unroll
+        for (int s = 0; s < NSW - 1; s++) stage_weights(s, 0, s);
+        // patch rows this lane fetches in every chunk: element offset of the row's chunk, or -1
+        int poff[kPatchPieces];
+#pragma unroll
+        for (int i = 0; i < kPatchPieces; i++) {
+            const int pr = (pw * kPatchPieces + i) * 8 + sub;
+            const int py = pr / PWH, px = pr - py * PWH;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            const bool ok = pr < NROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            poff[i] = ok ? (((n * H + iy) * W + ix) * C + (pos ^ (pr & 7)) * EPC) : -1;
+        }
+        auto stage_patch_piece = [&](int i, int chunk) {
+            const unsigned dst = patch_base + (chunk & 1) * P_BUF + (pw * kPatchPieces + i) * 1024;
+            glds16(poff[i] >= 0 ? in + (poff[i] + chunk * BK) : zero_src, dst);
+        };
+#pragma unroll
+        for (int i = 0; i < kPatchPieces; i++) stage_patch_piece(i, 0);
+        ts[1] = wall_clock64();
+
+        int slot = 0;  // ring slot of the current step
+        auto chunk_body = [&](auto last_tag, int c) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            static_for<0, 9>([&](auto t_tag) {
+                constexpr int t = decltype(t_tag)::value;
+                // the prologue issues the first patch AFTER the first weights: the
+                // first step also waits for everything issued so far (later steps then see only younger groups)
+                if (c == 0 && t == 0) wait_vmcnt<0>();
+                else wait_vmcnt<in_flight_ok(NSW, NI_W, LAST, t)>();
+                __builtin_amdgcn_s_barrier();  // step (c, t) is in LDS; step (c, t) - 1 has been read
+                asm volatile("" ::: "memory");
+                constexpr int tn = (t + NSW - 1) % 9, cn = (t + NSW - 1) / 9;
+                if (!LAST || cn == 0) stage_weights(tn, c + cn, slot == 0 ? NSW - 1 : slot - 1);
+                if (!LAST) {
+#pragma unroll
+                    for (int q = 0; q < pieces_at(NSW, t); q++) stage_patch_piece(pieces_before(NSW, t) + q, c + 1);
+                }
+                slot = slot + 1 == NSW ? 0 : slot + 1;
+            });
+        };
+        for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c);
+        chunk_body(std::true_type{}, nchunks - 1);
+        ts[2] = ts[3] = wall_clock64();
+    } else {
+        // ------------------------------------------------------------------ consumer waves
+        const int wc = wave >> 1, wpx = wave & 1;
+        const int g = lane >> 4, r16 = lane & 15;
+        // patch row under the centre tap of each of this lane's pixel columns
+        int pr_c[TP];
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            const int f = wpx * TP + tp;
+            pr_c[tp] = (f / FPR + 1) * PWH + (f % FPR) * 16 + r16 + 1;
+        }
+        const unsigned a_off = lds_base + wc * TC * 2048 + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
+
+        u32x4 fa[2][TC], fb[2][TP];  // fragments of the two K halves of a step
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++) fa[1][tc] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) fb[1][tp] = (u32x4){0u, 0u, 0u, 0u};
+
+        // multiply half `use` while the reads of half `load` are issued between the MFMAs
+        auto mma_and_read = [&](auto use_tag, unsigned wbase, const unsigned (&baddr)[TP], bool do_read) {
+            constexpr int USE = decltype(use_tag)::value, LOAD = 1 - USE;
+            const unsigned flip = LOAD ? 64u : 0u;
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) {
+#pragma unroll
+                for (int tp = 0; tp < TP; tp++) {
+                    Mma<T>::mma(__builtin_bit_cast(frag, fa[USE][tc]), __builtin_bit_cast(frag, fb[USE][tp]), acc[tc][tp]);
+                    const int k = tc * TP + tp;
+                    if (do_read) {
+                        if (k < TC) fa[LOAD][k] = lds_read16(wbase ^ flip, k * 2048);
+                        else if (k < TC + TP) fb[LOAD][k - TC] = lds_read16(baddr[k - TC] ^ flip, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        auto landed = [&](auto half_tag) {
+            constexpr int HALF = decltype(half_tag)::value;
+            lds_wait();
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) lds_landed(fa[HALF][tc]);
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) lds_landed(fb[HALF][tp]);
+        };
+        ts[1] = wall_clock64();
+
+        int slot = 0;
+        unsigned baddr[TP];
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) baddr[tp] = 0;
+        for (int c = 0; c < nchunks; c++) {
+            const unsigned pbuf = patch_base + (c & 1) * P_BUF;
+            static_for<0, 9>([&](auto t_tag) {
+                constexpr int t = decltype(t_tag)::value;
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (c == 0 && t == 0) ts[2] = wall_clock64();
+                const Tap tap = p.taps[t];
+                const int shift = tap.dy * PWH + tap.dx;
+                const unsigned wbase = a_off + slot * W_SLOT;
+#pragma unroll
+                for (int tp = 0; tp < TP; tp++) {
+                    const int pr = pr_c[tp] + shift;
+                    baddr[tp] = pbuf + pr * 128 + ((g ^ (pr & 7)) << 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // second half of the previous step under the reads of this step's first half
+                mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);
+                landed(std::integral_constant<int, 0>{});
+                mma_and_read(std::integral_constant<int, 0>{}, wbase, baddr, true);
+                landed(std::integral_constant<int, 1>{});  // every read of the step is back before the next barrier
+                slot = slot + 1 == NSW ? 0 : slot + 1;
+            });
+        }
+        mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
+        ts[3] = wall_clock64();
+    }
+
+    // epilogue
+    const long img = (long)n * H;
+    if (p.row_store_ok) {
+        conv_epilogue_lds<T, TC, TP, 2, 2, 512>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
+            const int f = pl >> 4;
+            const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (pl & 15);
+            return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
+        });
+    } else if (wave < 4) {
+        const int wc = wave >> 1, wpx = wave & 1;
+        const int g = lane >> 4, r16 = lane & 15;
+        conv_epilogue_at<T, TC, TP>(p, acc, co0, wc, g, [&](int tp) -> long {
+            const int f = wpx * TP + tp;
+            const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + r16;
+            return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
+        });
+    }
+    if ((p.dbg & 4) && blockIdx.x < 4096) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[4] = wall_clock64();
+        if (tid == 0 || tid == 256)
+            for (int i = 0; i < 5; i++) g_patch_times[(blockIdx.x * 2 + (tid >> 8)) * 8 + i] = ts[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static bool patch_eligible(const ConvGemmParams& p, int dtype) {
+    const int bk = dtype == STMI_BF16 ? 64 : 32;
+    if (p.ntaps != 9 || p.cdiv != 0 || p.klen <= 0 || p.klen % bk != 0 || p.klen != p.Ci) return false;
+    if (p.w_batch_stride != 0 || p.in_stride != 1 || p.oys != 1 || p.oxs != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
+    if (p.Hs != p.Hi || p.Ws != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi) return false;
+    if (p.co_pad % 64 != 0) return false;
+    if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31)) return false;
+    for (int t = 0; t < 9; t++)
+        if (p.taps[t].dy < -1 || p.taps[t].dy > 1 || p.taps[t].dx < -1 || p.taps[t].dx > 1) return false;
+    return true;
+}
+
+static int patch_width(const ConvGemmParams& p) { return p.Wi > 32 ? 64 : (p.Wi > 16 ? 32 : 16); }
+
+static long patch_tiles(const ConvGemmParams& p, int blk_co) {
+    const int pw = patch_width(p), ph = 128 / pw;
+    return (long)p.N * ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw) * (p.co_pad / blk_co);
+}
+
+// 128 output channels per block when that still gives every CU a block.
+// STMI_PATCH_CO=64|128 forces the choice (tuning aid).
+static int patch_blk_co(const ConvGemmParams& p) {
+    const char* force = getenv("STMI_PATCH_CO");
+    if (force) {
+        const int c = atoi(force);
+        if ((c == 64 || c == 128) && p.co_pad % c == 0) return c;
+    }
+    return p.co_pad % 128 == 0 && patch_tiles(p, 128) >= 256 ? 128 : 64;
+}
+
+template <typename T, int TC, int PW, int NSW>
+static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
+    constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * 4 * kPatchPieces * 8 * 128;
+    static bool attr_set = false;  // idempotent; a racing second call is harmless
+    if (!attr_set) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_kernel<T, TC, PW, NSW>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
+                           "hipFuncSetAttribute(conv_patch_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const long tiles = patch_tiles(p, 32 * TC);
+    if (tiles <= 0) return STMI_OK;
+    ConvGemmParams q = p;
+    const char* dbg = getenv("STMI_PATCH_DBG");
+    q.dbg = dbg ? atoi(dbg) : 0;
+    STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
+    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW>), dim3((unsigned)tiles), dim3(512), kLds, s, q);
+    STMI_LAUNCH_CHECK("conv_patch_kernel");
+    return STMI_OK;
+}
+
+template <typename T, int TC>
+static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
+    switch (patch_width(p)) {
+        case 64: return launch_patch<T, TC, 64, 4>(p, s);
+        case 32: return launch_patch<T, TC, 32, 4>(p, s);
+        default: return launch_patch<T, TC, 16, 4>(p, s);
+    }
+}
+
+bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
+    if (!patch_eligible(p, dtype) || getenv("STMI_NO_PATCH")) return false;
+    const int co = patch_blk_co(p);
+    if (name)
+        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4>(stmi::ConvGemmParams)",
+                 dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p));
+    if (dtype == STMI_BF16)
+        *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s) : launch_patch_w<bf16_t, 2>(p, s);
+    else
+        *rc = co == 128 ? launch_patch_w<float, 4>(p, s) : launch_patch_w<float, 2>(p, s);
+    return true;
+}
+
+int debug_patch_times(long* host, int n) {
+    return check_hip(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_patch_times), (size_t)n * sizeof(long)), "memcpy from symbol");
+}
+
+}  // namespace stmi
+
+extern "C" int stmi_debug_patch_times(long* host, int n) { return stmi::debug_patch_times(host, n); }

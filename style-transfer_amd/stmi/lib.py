@@ -22,7 +22,7 @@ SIGNATURES = {
     'stmi_version': (_c_int, []),
     'stmi_last_error': (ctypes.c_char_p, []),
     'stmi_device_arch': (_c_int, [ctypes.c_char_p, _c_int]),
-    'stmi_conv_kernel_name': (_c_int, [_c_int, _c_long, _c_int, _c_int, ctypes.c_char_p, _c_int]),
+    'stmi_last_conv_kernel': (_c_int, [ctypes.c_char_p, _c_int]),
     'stmi_conv_packed_elems': (_c_long, [_c_int] * 5),
     'stmi_pack_conv_weights': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),

@@ -50,10 +50,11 @@ def same_out(size, stride):
 PROFILE = None
 
 
-def _kernel_name(out_channels, out_pixels, k_channels, dtype_code):
+def last_conv_kernel():
+    """Profiler name of the kernel the most recent conv forward / backward-data call launched."""
     import ctypes
     buf = ctypes.create_string_buffer(256)
-    _lib.call('stmi_conv_kernel_name', out_channels, out_pixels, k_channels, dtype_code, buf, 256)
+    _lib.call('stmi_last_conv_kernel', buf, 256)
     return buf.value.decode()
 
 
@@ -61,7 +62,6 @@ class _Timed:
     def __init__(self, out_channels, out_pixels, k_channels, taps, dtype_code, stride):
         self.on = PROFILE is not None and stride == 1
         if self.on:
-            self.name = _kernel_name(out_channels, out_pixels, k_channels, dtype_code)
             self.flops = 2.0 * out_channels * out_pixels * k_channels * taps
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
@@ -73,7 +73,7 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((last_conv_kernel(), self.flops, self.e0, self.e1))
 
 
 # ---------------------------------------------------------------- weights

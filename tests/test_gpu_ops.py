@@ -42,6 +42,13 @@ CONV_CASES = [
     (1, 7, 9, 3, 64, 3, 1),       # VGG conv1_1
     (1, 6, 5, 256, 512, 3, 1),    # VGG conv4_1
     (3, 5, 5, 8, 16, 3, 1),       # reduced-width VGG layer
+    # LDS-resident patch kernel (3x3, stride 1, >= 128 bytes of channels): every patch width,
+    # ragged edges in both directions, several tiles per image, several channel chunks
+    (1, 5, 70, 64, 64, 3, 1),
+    (2, 11, 40, 128, 64, 3, 1),
+    (1, 20, 130, 64, 192, 3, 1),
+    (2, 17, 16, 192, 128, 3, 1),
+    (1, 3, 2, 64, 64, 3, 1),
 ]
 
 
@@ -73,10 +80,12 @@ def test_conv_fwd_dgrad_wgrad(cuda, dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
-def test_conv_dgrad_epilogue(cuda, dtype):
-    """alpha, ReLU mask and addend of the backward-data epilogue."""
+@pytest.mark.parametrize('chans', [(16, 32), (64, 128)], ids=['gather', 'patch'])
+def test_conv_dgrad_epilogue(cuda, dtype, chans):
+    """alpha, ReLU mask and addend of the backward-data epilogue (both kernel families)."""
     from stmi import ops
-    n, h, w, ci, co, k, s = 2, 8, 6, 16, 32, 3, 1
+    n, h, w, k, s = 2, 8, 6, 3, 1
+    ci, co = chans
     wt = rnd((k, k, ci, co), 2, 0.1)
     dy = rnd((n, h, w, co), 4)
     mask = rnd((n, h, w, ci), 5)
