@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         }
     }
 
-    conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wc, wpx, g, r16, Mz, zoff, HWs);
+    conv_epilogue_linear<T, TC, TP, WC, WP, (int)sizeof(lds)>(p, acc, co0, pix0, Mz, zoff, HWs, lds);
 }
 
 // ---------------------------------------------------------------------------

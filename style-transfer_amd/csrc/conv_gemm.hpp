@@ -122,19 +122,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, const f32
 // accumulators' native layout gives each lane 4 channels of one pixel, i.e. 8-byte stores
 // into sixteen different pixel rows per wave-instruction, and sixteen of those per lane
 // cost about 5 us of store issue.  Staged as fp32 [pixel][channel] in LDS and read back
-// row-wise, every wave-instruction instead stores whole 128/256-byte pixel rows, 16 bytes
-// per lane.  Needs Co a multiple of the 16-byte vector and 16-byte aligned tensors
-// (p.row_store_ok); pixel_offset(local pixel) is the element offset in the written tensor
-// or negative.  All NT threads of the block must call it (waves past WC*WP only store); `stage` is BLK_PIX * (BLK_CO + 4) floats.
-template <typename T, int TC, int TP, int WC, int WP, int NT, typename PixelOffset>
+// row-wise, every wave-instruction instead stores whole pixel rows, 16 bytes per lane.
+// The tile goes through the staging area TPG pixel fragments (per wave) at a time, so the
+// area is 16*TPG*WP * (BLK_CO + 4) floats: conv_stage_tpg() picks the largest TPG that fits.
+// Needs Co a multiple of the 16-byte vector and 16-byte aligned tensors (p.row_store_ok);
+// pixel_offset(local pixel) is the element offset in the written tensor or negative.  All NT
+// threads of the block must call it (waves past WC*WP only store).
+constexpr int conv_stage_tpg(int tc, int tp, int wc, int wp, int lds_bytes) {
+    int best = 0;
+    for (int g = 1; g <= tp; g++)
+        if (tp % g == 0 && 16 * g * wp * (16 * tc * wc + 4) * 4 <= lds_bytes) best = g;
+    return best;
+}
+
+template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, typename PixelOffset>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
                                                   float* stage, PixelOffset pixel_offset) {
     constexpr int EPC = 16 / sizeof(T);
-    constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
+    constexpr int BLK_CO = 16 * TC * WC;
     constexpr int STRIDE = BLK_CO + 4;   // floats; +16 bytes keeps the 16-byte writes conflict-free
     constexpr int LPR = BLK_CO / EPC;    // lanes per pixel row
     constexpr int RPP = NT / LPR;        // pixel rows per pass of the block
-    static_assert(BLK_PIX % RPP == 0, "tile rows must split over the passes");
+    constexpr int ROWS = 16 * TPG * WP;  // pixel rows per group
+    static_assert(TPG >= 1 && TP % TPG == 0, "fragment groups must tile the wave's pixels");
+    static_assert(BLK_CO % EPC == 0 && NT % LPR == 0, "row pieces must tile the block");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WP, wpx = wave % WP;
     const int g = lane >> 4, r16 = lane & 15;
@@ -142,58 +153,92 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
     T* __restrict__ out_pre = (T*)p.out_pre;
     const T* __restrict__ mask = (const T*)p.mask;
     const T* __restrict__ addend = (const T*)p.addend;
+    const int cl_rd = (tid % LPR) * EPC;
+    const bool col_ok = co0 + cl_rd < p.Co;
 
-    __syncthreads();  // every wave is done reading operand tiles
+    f32x4 bias_r[TC];
 #pragma unroll
     for (int tc = 0; tc < TC; tc++) {
-        if (wave >= WC * WP) break;  // waves beyond the MFMA grid hold no accumulators
-        const int cl = (wc * TC + tc) * 16 + 4 * g;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
+        bias_r[tc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int co = co0 + (wc * TC + tc) * 16 + 4 * g;
+        if (p.bias && wave < WC * WP) {
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (co0 + cl + u < p.Co) b[u] = p.bias[co0 + cl + u];
-        }
-#pragma unroll
-        for (int tp = 0; tp < TP; tp++) {
-            const int pl = (wpx * TP + tp) * 16 + r16;
-            *reinterpret_cast<f32x4*>(stage + pl * STRIDE + cl) = (acc[tc][tp] + b) * p.alpha;
+                if (co + u < p.Co) bias_r[tc][u] = p.bias[co + u];
         }
     }
-    __syncthreads();
-    const int cl = (tid % LPR) * EPC;
-    if (co0 + cl >= p.Co) return;
 #pragma unroll
-    for (int pass = 0; pass < BLK_PIX / RPP; pass++) {
-        const int pl = pass * RPP + tid / LPR;
-        const long off = pixel_offset(pl);
-        if (off < 0) continue;
-        const long e = off + co0 + cl;
-        float v[EPC];
+    for (int tp0 = 0; tp0 < TP; tp0 += TPG) {
+        __syncthreads();  // operand tiles (first group) or the previous group's rows are consumed
+        if (wave < WC * WP) {
 #pragma unroll
-        for (int u = 0; u < EPC; u += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(stage + pl * STRIDE + cl + u);
-            v[u] = t[0]; v[u + 1] = t[1]; v[u + 2] = t[2]; v[u + 3] = t[3];
+            for (int tc = 0; tc < TC; tc++) {
+                const int cl = (wc * TC + tc) * 16 + 4 * g;
+#pragma unroll
+                for (int t = 0; t < TPG; t++) {
+                    const int rr = (wpx * TPG + t) * 16 + r16;
+                    *reinterpret_cast<f32x4*>(stage + rr * STRIDE + cl) = (acc[tc][tp0 + t] + bias_r[tc]) * p.alpha;
+                }
+            }
         }
-        if (mask) {
-            float mk[EPC];
-            load_vec<T, EPC>(mask + e, mk);
+        __syncthreads();
+        if (!col_ok) continue;
+        for (int rr = tid / LPR; rr < ROWS; rr += RPP) {
+            const int w_ = rr / (16 * TPG), rem = rr - w_ * (16 * TPG);
+            const int pl = (w_ * TP + tp0 + (rem >> 4)) * 16 + (rem & 15);
+            const long off = pixel_offset(pl);
+            if (off < 0) continue;
+            const long e = off + co0 + cl_rd;
+            float v[EPC];
 #pragma unroll
-            for (int u = 0; u < EPC; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
-        }
-        if (addend) {
-            float ad[EPC];
-            load_vec<T, EPC>(addend + e, ad);
+            for (int u = 0; u < EPC; u += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(stage + rr * STRIDE + cl_rd + u);
+                v[u] = t[0]; v[u + 1] = t[1]; v[u + 2] = t[2]; v[u + 3] = t[3];
+            }
+            if (mask) {
+                float mk[EPC];
+                load_vec<T, EPC>(mask + e, mk);
 #pragma unroll
-            for (int u = 0; u < EPC; u++) v[u] += ad[u];
-        }
-        if (out_pre) store_vec<T, EPC>(out_pre + e, v);
-        if (p.relu) {
+                for (int u = 0; u < EPC; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
+            }
+            if (addend) {
+                float ad[EPC];
+                load_vec<T, EPC>(addend + e, ad);
 #pragma unroll
-            for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
+                for (int u = 0; u < EPC; u++) v[u] += ad[u];
+            }
+            if (out_pre) store_vec<T, EPC>(out_pre + e, v);
+            if (p.relu) {
+#pragma unroll
+                for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
+            }
+            store_vec<T, EPC>(out + e, v);
         }
-        store_vec<T, EPC>(out + e, v);
     }
+}
+
+// Epilogue of the gather-GEMM kernels (256 threads, WC x WP waves): row-wise through the
+// block's LDS (LDS_BYTES of it at `stage`) when the tensors allow it, lane-wise otherwise.
+template <typename T, int TC, int TP, int WC, int WP, int LDS_BYTES>
+__device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
+                                                     long pix0, long Mz, long zoff, int HWs, void* stage) {
+    constexpr int TPG = conv_stage_tpg(TC, TP, WC, WP, LDS_BYTES);
+    if constexpr (TPG > 0) {
+        if (p.row_store_ok) {
+            conv_epilogue_lds<T, TC, TP, WC, WP, 256, TPG>(p, acc, co0, reinterpret_cast<float*>(stage), [&](int pl) -> long {
+                const long m = pix0 + pl;
+                if (m >= Mz) return -1;
+                const long mm = m + zoff;
+                const int n = (int)(mm / HWs);
+                const int rem = (int)(mm - (long)n * HWs);
+                const int i = rem / p.Ws, j = rem - i * p.Ws;
+                return (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
+            });
+            return;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wave / WP, wave % WP, lane >> 4, lane & 15, Mz, zoff, HWs);
 }
 
 // LDS-DMA variant (conv_gemm_glds.hip).  Returns true and launches when the problem fits

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const ConvGemmParam
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
     }
-    conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wc, wpx, g, r16, Mz, zoff, HWs);
+    conv_epilogue_linear<T, TC, TP, WC, WP, NS * STAGE * 16>(p, acc, co0, pix0, Mz, zoff, HWs, lds);
 }
 
 // ---------------------------------------------------------------------------

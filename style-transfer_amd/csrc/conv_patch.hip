@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     // epilogue
     const long img = (long)n * H;
     if (p.row_store_ok) {
-        conv_epilogue_lds<T, TC, TP, 2, 2, 512>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
+        conv_epilogue_lds<T, TC, TP, 2, 2, 512, TP>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
             const int f = pl >> 4;
             const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (pl & 15);
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
