@@ -24,6 +24,8 @@ for name, hh, w, ci, co, pco in [('vgg1_2', 256, 256, 64, 64, '64'), ('vgg3_x', 
     nb = min(4096, B * (hh // (128 // min(64, w))) * (w // min(64, w)) * (co // int(pco)))
     full = full[:nb]
     t0 = full[:, :, 0].min()
+    pf = full[:, 1, :]
+    print('   producer setup: decode+offsets-w %.2f  W0-issue %.2f  poff %.2f  pieces+W12 %.2f' % ((pf[:, 5] - pf[:, 0]).mean(), (pf[:, 6] - pf[:, 5]).mean(), (pf[:, 7] - pf[:, 6]).mean(), (pf[:, 1] - pf[:, 7]).mean()))
     for role, nm in ((0, 'consumer'), (1, 'producer')):
         t = full[:, role, :5]
         d_ = np.diff(t, axis=1)

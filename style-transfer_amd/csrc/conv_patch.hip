@@ -59,6 +59,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+constexpr int kProloguePieces = 5;  // pieces of the FIRST patch the producer wave issues itself
 constexpr int kPatchPieces = 9;  // 8-row DMA pieces per wave and chunk: 4 * 9 * 8 = 288 patch rows
 
 // pieces of the NEXT chunk's patch a wave issues in tap iteration t (they must land with the
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     const unsigned patch_base = lds_base + NSW * W_SLOT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long ts[5];
+    long ts[8];
     ts[0] = wall_clock64();
     const int H = p.Hi, W = p.Wi, C = p.Ci;
 
@@ -121,14 +122,17 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
         tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
     }
-    const unsigned n_co = p.co_pad / BLK_CO;
-    const unsigned tiles_x = (W + PW - 1) / PW, tiles_y = (H + PH - 1) / PH;
-    const int co0 = (tile % n_co) * BLK_CO;
-    unsigned tp_id = tile / n_co;
-    const int tx0 = (tp_id % tiles_x) * PW;
-    tp_id /= tiles_x;
-    const int ty0 = (tp_id % tiles_y) * PH;
-    const int n = tp_id / tiles_y;
+    // divisions by host-provided reciprocals (exact for the operand range the launcher checked)
+    auto div_by = [&](unsigned a, int i) -> unsigned {
+        return p.pt_magic[i] ? __umulhi(a, p.pt_magic[i]) : (p.pt_div[i] == 1 ? a : a / p.pt_div[i]);
+    };
+    unsigned tp_id = div_by(tile, 0);
+    const int co0 = (tile - tp_id * p.pt_div[0]) * BLK_CO;
+    unsigned q = div_by(tp_id, 1);
+    const int tx0 = (tp_id - q * p.pt_div[1]) * PW;
+    const unsigned n_img = div_by(q, 2);
+    const int ty0 = (q - n_img * p.pt_div[2]) * PH;
+    const int n = (int)n_img;
     const int nchunks = p.klen / BK;
 
     f32x4 acc[TC][TP];
@@ -160,25 +164,46 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 #pragma unroll
             for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], dst + j * 1024);
         };
-        // the weights of steps 0 .. NSW-2 need no per-pixel arithmetic: start them first
-#pragma unroll
-        for (int s = 0; s < NSW - 1; s++) stage_weights(s, 0, s);
-        // patch rows this lane fetches in every chunk: element offset of the row's chunk, or -1
+        ts[5] = wall_clock64();
+        stage_weights(0, 0, 0);
+        ts[6] = wall_clock64();
+        // patch rows this lane fetches in every chunk: element offset of the row's chunk, or -1.
+        // Consecutive pieces are 8 patch rows apart: one division, then steps.
         int poff[kPatchPieces];
+        {
+            int pr = pw * kPatchPieces * 8 + sub;
+            const int py0 = pr / PWH;
+            int px = pr - py0 * PWH;
+            int iy = ty0 - 1 + py0, ix = tx0 - 1 + px;
+            const int swz = (pos ^ (sub & 7)) * EPC;  // pr & 7 == sub for every piece
+            const int step = 8 * C, wrap = (W - PWH) * C;
+            int lin = ((n * H + iy) * W + ix) * C + swz;
 #pragma unroll
-        for (int i = 0; i < kPatchPieces; i++) {
-            const int pr = (pw * kPatchPieces + i) * 8 + sub;
-            const int py = pr / PWH, px = pr - py * PWH;
-            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            const bool ok = pr < NROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            poff[i] = ok ? (((n * H + iy) * W + ix) * C + (pos ^ (pr & 7)) * EPC) : -1;
+            for (int i = 0; i < kPatchPieces; i++) {
+                const bool ok = pr < NROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                poff[i] = ok ? lin : -1;
+                pr += 8;
+                px += 8;
+                ix += 8;
+                lin += step;
+                const bool w = px >= PWH;
+                px -= w ? PWH : 0;
+                ix -= w ? PWH : 0;
+                iy += w ? 1 : 0;
+                lin += w ? wrap : 0;
+            }
         }
         auto stage_patch_piece = [&](int i, int chunk) {
             const unsigned dst = patch_base + (chunk & 1) * P_BUF + (pw * kPatchPieces + i) * 1024;
             glds16(poff[i] >= 0 ? in + (poff[i] + chunk * BK) : zero_src, dst);
         };
+        ts[7] = wall_clock64();
+        // The first patch is split with the consumer wave of the same index (idle until the
+        // first barrier): issuing a piece costs the issuing wave 60-180 cycles.
 #pragma unroll
-        for (int i = 0; i < kPatchPieces; i++) stage_patch_piece(i, 0);
+        for (int i = 0; i < kProloguePieces; i++) stage_patch_piece(i, 0);
+#pragma unroll
+        for (int s = 1; s < NSW - 1; s++) stage_weights(s, 0, s);
         ts[1] = wall_clock64();
 
         int slot = 0;  // ring slot of the current step
@@ -186,10 +211,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             constexpr bool LAST = decltype(last_tag)::value;
             static_for<0, 9>([&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
-                // the prologue issues the first patch AFTER the first weights: the
-                // first step also waits for everything issued so far (later steps then see only younger groups)
-                if (c == 0 && t == 0) wait_vmcnt<0>();
-                else wait_vmcnt<in_flight_ok(NSW, NI_W, LAST, t)>();
+                wait_vmcnt<in_flight_ok(NSW, NI_W, LAST, t)>();
                 __builtin_amdgcn_s_barrier();  // step (c, t) is in LDS; step (c, t) - 1 has been read
                 asm volatile("" ::: "memory");
                 constexpr int tn = (t + NSW - 1) % 9, cn = (t + NSW - 1) / 9;
@@ -216,6 +238,21 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             pr_c[tp] = (f / FPR + 1) * PWH + (f % FPR) * 16 + r16 + 1;
         }
         const unsigned a_off = lds_base + wc * TC * 2048 + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
+        // this wave's share of the first patch (the producer wave of the same index takes the rest)
+        {
+            const int sub = lane >> 3, pos = lane & 7;
+            const T* in = (const T*)p.in;
+#pragma unroll
+            for (int i = kProloguePieces; i < kPatchPieces; i++) {
+                const int pr = (wave * kPatchPieces + i) * 8 + sub;
+                const int py = pr / PWH, px = pr - py * PWH;
+                const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+                const bool ok = pr < NROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const T* src = ok ? in + (((n * H + iy) * W + ix) * C + (pos ^ (pr & 7)) * EPC)
+                                  : (const T*)(g_patch_zero_page + pos);
+                glds16(src, patch_base + (wave * kPatchPieces + i) * 1024);
+            }
+        }
 
         u32x4 fa[2][TC], fb[2][TP];  // fragments of the two K halves of a step
 #pragma unroll
@@ -232,10 +269,15 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 #pragma unroll
                 for (int tp = 0; tp < TP; tp++) {
                     Mma<T>::mma(__builtin_bit_cast(frag, fa[USE][tc]), __builtin_bit_cast(frag, fb[USE][tp]), acc[tc][tp]);
-                    const int k = tc * TP + tp;
+                    // reads go behind the first MFMAs so that the rest of the block covers their
+                    // latency: one per MFMA when there are sixteen MFMAs, two when there are eight
                     if (do_read) {
-                        if (k < TC) fa[LOAD][k] = lds_read16(wbase ^ flip, k * 2048);
-                        else if (k < TC + TP) fb[LOAD][k - TC] = lds_read16(baddr[k - TC] ^ flip, 0);
+                        constexpr int RPG = TC * TP >= 16 ? 1 : 2;
+#pragma unroll
+                        for (int k = RPG * (tc * TP + tp); k < RPG * (tc * TP + tp + 1); k++) {
+                            if (k < TC) fa[LOAD][k] = lds_read16(wbase ^ flip, k * 2048);
+                            else if (k < TC + TP) fb[LOAD][k - TC] = lds_read16(baddr[k - TC] ^ flip, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -259,6 +301,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             const unsigned pbuf = patch_base + (c & 1) * P_BUF;
             static_for<0, 9>([&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
+                if (c == 0 && t == 0) wait_vmcnt<0>();  // own share of the first patch
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (c == 0 && t == 0) ts[2] = wall_clock64();
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = wall_clock64();
         if (tid == 0 || tid == 256)
-            for (int i = 0; i < 5; i++) g_patch_times[(blockIdx.x * 2 + (tid >> 8)) * 8 + i] = ts[i];
+            for (int i = 0; i < 8; i++) g_patch_times[(blockIdx.x * 2 + (tid >> 8)) * 8 + i] = ts[i];
     }
 }
 
@@ -357,6 +400,16 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     ConvGemmParams q = p;
     const char* dbg = getenv("STMI_PATCH_DBG");
     q.dbg = dbg ? atoi(dbg) : 0;
+    {
+        constexpr int PH = 128 / PW;
+        const unsigned div[3] = {(unsigned)(p.co_pad / (32 * TC)), (unsigned)ceil_div(p.Wi, PW), (unsigned)ceil_div(p.Hi, PH)};
+        for (int i = 0; i < 3; i++) {
+            q.pt_div[i] = div[i];
+            // ceil(2^32 / d) gives exact quotients while dividend * d < 2^32
+            const bool fits = div[i] > 1 && (unsigned long)tiles * div[i] < (1UL << 32);
+            q.pt_magic[i] = fits ? (unsigned)(((1UL << 32) + div[i] - 1) / div[i]) : 0u;
+        }
+    }
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
     hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW>), dim3((unsigned)tiles), dim3(512), kLds, s, q);
     STMI_LAUNCH_CHECK("conv_patch_kernel");

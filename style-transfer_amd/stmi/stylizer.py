@@ -143,7 +143,11 @@ class StylizerNet:
             self._pool = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(4)]
         else:
             biggest = max(batch * b.out_h * b.out_w * b.co for b in self.blocks)
-            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(4)]
+            # Gradient buffers: g, the skip gradient, dconv, dx -- and two more, so that a weight
+            # gradient still reading an older dconv on the side stream does not hold up the chain.
+            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(6)]
+            self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+            self._readers = {}  # data_ptr of a gradient buffer -> event after its last side-stream reader
         self.repack()
 
     # ------------------------------------------------------------ parameters
@@ -203,8 +207,9 @@ class StylizerNet:
     # -------------------------------------------------------------- backward
     def backward(self, d_out, hi=None, lo=0):
         """d_out: gradient w.r.t. the stylized image, compute dtype [n,h,w,3].
-        Parameter gradients are written (W) or added (shift/scale) into
-        self.flat_grad, which the caller zeroes once per step.
+        Parameter gradients are ADDED into self.flat_grad, which the caller zeroes
+        once per step; the weight-gradient kernels run on a side stream beside the
+        data-gradient chain and are joined before the call returns.
 
         The pass can be cut into block ranges so that a data-parallel caller can
         start reducing the gradients of finished blocks: backward(d_out, hi=15,
@@ -217,32 +222,60 @@ class StylizerNet:
             self._bstate = (d_out, None)
         g, pending_skip = self._bstate  # pending_skip: gradient flowing along a residual connection
         bufs = self._g
+        main, side = torch.cuda.current_stream(), self._side
+
+        def writable(exclude):
+            """Two buffers to overwrite: ones no weight-gradient kernel is still reading come first."""
+            free = [p for p in bufs if p.data_ptr() not in exclude]
+            free.sort(key=lambda p: p.data_ptr() in self._readers)
+            for p in free[:2]:
+                ev = self._readers.pop(p.data_ptr(), None)
+                if ev is not None:
+                    main.wait_event(ev)
+            return free[0], free[1]
+
+        def on_side(buf, fn):
+            """The parameter-gradient kernels only feed the optimizer: they run beside the chain."""
+            if side is None:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self._readers[buf.data_ptr()] = ev
+
         for i in range(hi, lo - 1, -1):
             b = self.blocks[i]
             x_in = self.blocks[i - 1].y if i > 0 else self.x_in
-            free = [p for p in bufs if p.data_ptr() not in
-                    (g.data_ptr(), None if pending_skip is None else pending_skip.data_ptr())]
-            dconv = self._view(free[0], b)
+            w0, w1 = writable((g.data_ptr(), None if pending_skip is None else pending_skip.data_ptr()))
+            dconv = self._view(w0, b)
             if b.role == 'b':
                 pending_skip = g  # d(block input) receives d(block output) unchanged
             ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act,
                                   ws=self.ws, out=dconv)
             rows_g = None
             if b.kind == 'deconv':
-                ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
+                on_side(w0, lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True))
             elif b.rows == 'in':      # rows_buf still holds the forward's input patches
-                ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
-                ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
+                def wg_in():
+                    ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
+                    ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
+                on_side(w0, wg_in)
             elif b.rows == 'out':
                 rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
-                ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
-                ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
+
+                def wg_out():
+                    ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
+                    ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
+                on_side(w0, wg_out)
             else:
-                ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
+                on_side(w0, lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True))
             if i == 0:
                 break
             n_in = self.n * b.in_h * b.in_w * b.ci
-            dx = free[1][:n_in].view(self.n, b.in_h, b.in_w, b.ci)
+            dx = w1[:n_in].view(self.n, b.in_h, b.in_w, b.ci)
             addend = pending_skip if b.role == 'a' else None
             if b.kind == 'deconv':
                 ops.conv2d_transpose_dgrad(dconv, b.wp_bwd, b.kshape, b.s, addend=addend, out=dx)
@@ -253,6 +286,10 @@ class StylizerNet:
             if b.role == 'a':
                 pending_skip = None
             g = dx
+        # the caller reduces / applies the gradients of this range next: join the side stream
+        if side is not None:
+            main.wait_stream(side)
+            self._readers.clear()
         self._bstate = (g, pending_skip)
 
     def param_range(self, hi, lo):

@@ -72,6 +72,8 @@ class StyleTrainer:
             self.buckets = GradBuckets(self.net.flat_grad, [self.net.param_range(hi, lo) for hi, lo in BWD_SEGMENTS],
                                        group)
         self._graphs = None
+        # the content targets only meet the rest of the step at the content loss
+        self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
 
     # ------------------------------------------------------------- targets
     def set_style_image(self, style_f32):
@@ -87,10 +89,16 @@ class StyleTrainer:
     def _front(self):
         self.losses.zero_()
         self.net.flat_grad.zero_()
-        _, content_target = self.rep_content.forward(self.batch_in, want_grams=False)
+        cs = self._content_stream
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                self.rep_content.forward(self.batch_in, want_grams=False)
+        else:
+            self.rep_content.forward(self.batch_in, want_grams=False)
         out = self.net.forward(self.batch_in)
-        d_out = self.rep_loss.loss_and_grad(out, self.style_targets, content_target,
-                                            self.sw, self.cw, self.tvw, self.losses)
+        d_out = self.rep_loss.loss_and_grad(out, self.style_targets, self.rep_content.content,
+                                            self.sw, self.cw, self.tvw, self.losses, content_stream=cs)
         return d_out
 
     def _update(self):

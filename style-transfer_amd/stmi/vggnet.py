@@ -98,6 +98,10 @@ class VggReplica:
             self.d_content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
             self.d_image = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
             self.tv_grad = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+        # Gram matrices and their loss terms hang off the conv chain as leaves: with kept
+        # (dedicated) tap buffers they run on a side stream beside the following layers.
+        self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' else None
+        self._style_job = None
 
     def _buf(self, pool, shape, avoid):
         n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -107,9 +111,13 @@ class VggReplica:
         raise RuntimeError('no free scratch buffer')
 
     # --------------------------------------------------------------- forward
-    def forward(self, x_f32, want_grams=True):
-        """Fills self.grams (5 x fp32 [n,c,c]) and self.content from an fp32 image batch in [0,1]."""
+    def forward(self, x_f32, want_grams=True, style_job=None):
+        """Fills self.grams (5 x fp32 [n,c,c]) and self.content from an fp32 image batch in [0,1].
+
+        style_job(li): optional follow-up of Gram li (its loss term), launched right behind
+        it on the same stream."""
         self._want_grams = want_grams
+        self._style_job = style_job
         net = self.net
         ops.scale_shift(x_f32, net.mean, 255.0 / 2.0, net.dtype, out=self.x_pre)
         cur = self.x_pre
@@ -155,31 +163,51 @@ class VggReplica:
         if tensor is None:
             return
         if name in self.style_names and self._want_grams:
-            ops.gram_fwd(tensor, out=self.grams[self.style_names.index(name)])
+            li = self.style_names.index(name)
+            if self._side is not None:
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    ops.gram_fwd(tensor, out=self.grams[li])
+                    if self._style_job is not None:
+                        self._style_job(li)
+            else:
+                ops.gram_fwd(tensor, out=self.grams[li])
+                if self._style_job is not None:
+                    self._style_job(li)
         if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
             self.content.copy_(tensor)
 
     # -------------------------------------------------------- loss + backward
-    def loss_and_grad(self, x_f32, style_targets, content_target, style_weight, content_weight, tv_weight, losses):
+    def loss_and_grad(self, x_f32, style_targets, content_target, style_weight, content_weight, tv_weight, losses,
+                      content_stream=None):
         """Runs forward on x_f32, ADDS [total, style, content, tv] into `losses` (fp32 [4], device,
         zeroed by the caller) and returns d(total)/d(x) in the compute dtype.
 
-        style_targets: 5 fp32 [c,c] (or [1,c,c]) Grams, content_target: tensor shaped like the content tap."""
+        style_targets: 5 fp32 [c,c] (or [1,c,c]) Grams, content_target: tensor shaped like the content tap;
+        content_stream: stream that is still producing content_target (joined before its first use)."""
         assert self.keep
         net, n = self.net, self.n
-        self.forward(x_f32)
         l_style, l_content, l_tv = losses[1:2], losses[2:3], losses[3:4]
+
         # style: sum_l mean((G_l - T_l)^2) * w / len(content outputs)   (model_utilities.py:396)
-        for li, nm in enumerate(self.style_names):
+        def style_term(li):
+            nm = self.style_names[li]
             c = self.shape[nm][3]
             hw = self.shape[nm][1] * self.shape[nm][2]
             ls = style_weight / float(n * c * c)
             ops.gram_mse_fwd_bwd(self.grams[li], style_targets[li], l_style, ls, 4.0 * ls / hw, net.dtype,
                                  out=self.s_packed[li])
+
+        ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+        self.forward(x_f32, style_job=style_term)
+        self._style_job = None
+        if content_stream is not None:
+            torch.cuda.current_stream().wait_stream(content_stream)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         cnt = self.content.numel()
         ops.mse_fwd_bwd(self.content, content_target, l_content, content_weight / cnt, 2.0 * content_weight / cnt,
                         out=self.d_content)
-        ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
 
         # backward through the truncated VGG; g is always the gradient w.r.t. a conv's pre-ReLU output
         names = net.names
