@@ -14,6 +14,7 @@
 namespace stmi {
 
 constexpr int kInMaxSplits = 256;
+constexpr int kInPpt = 4;  // pixels a thread keeps in flight
 
 struct InGeom {
     int N, HW, C, S, chunk;  // S slices of `chunk` pixels per sample
@@ -71,14 +72,23 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
     if (active) {
         load_vec<T, V>(xs + cg * V, k);
         const int pend = min(g.HW, (s + 1) * g.chunk);
-        for (int pix = s * g.chunk + slot; pix < pend; pix += slots) {
-            float v[V];
-            load_vec<T, V>(xs + (long)pix * g.C + cg * V, v);
+        // kInPpt loads in flight per thread: at these sizes the pass is bound by latency, not bytes
+        for (int pix0 = s * g.chunk + slot; pix0 < pend; pix0 += slots * kInPpt) {
+            float v[kInPpt][V];
 #pragma unroll
-            for (int j = 0; j < V; j++) {
-                const float d = v[j] - k[j];
-                s1[j] += d;
-                s2[j] += d * d;
+            for (int u = 0; u < kInPpt; u++) {
+                const int pix = pix0 + u * slots;
+                if (pix < pend) load_vec<T, V>(xs + (long)pix * g.C + cg * V, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kInPpt; u++) {
+                if (pix0 + u * slots >= pend) continue;
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    const float d = v[u][j] - k[j];
+                    s1[j] += d;
+                    s2[j] += d * d;
+                }
             }
         }
     }
@@ -140,20 +150,31 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
         b[j] = shift[c] - mean * a[j];
     }
     const long sample = (long)n * g.HW * g.C;
-    for (int pix = blockIdx.x * slots + slot; pix < g.HW; pix += gridDim.x * slots) {
-        const long off = sample + (long)pix * g.C + cg * V;
-        float v[V];
-        load_vec<T, V>(x + off, v);
+    const int stride = gridDim.x * slots;
+    for (int pix0 = blockIdx.x * slots + slot; pix0 < g.HW; pix0 += stride * kInPpt) {
+        float v[kInPpt][V], r[kInPpt][V];
 #pragma unroll
-        for (int j = 0; j < V; j++) v[j] = act_fwd(a[j] * v[j] + b[j], act);
-        if (residual) {
-            float r[V];
-            load_vec<T, V>(residual + off, r);
-#pragma unroll
-            for (int j = 0; j < V; j++) v[j] += r[j];
+        for (int u = 0; u < kInPpt; u++) {
+            const int pix = pix0 + u * stride;
+            if (pix >= g.HW) continue;
+            const long off = sample + (long)pix * g.C + cg * V;
+            load_vec<T, V>(x + off, v[u]);
+            if (residual) load_vec<T, V>(residual + off, r[u]);
         }
-        store_vec<T, V>(y + off, v);
-        if (y_f32) store_vec<float, V>(y_f32 + off, v);
+#pragma unroll
+        for (int u = 0; u < kInPpt; u++) {
+            const int pix = pix0 + u * stride;
+            if (pix >= g.HW) continue;
+            const long off = sample + (long)pix * g.C + cg * V;
+#pragma unroll
+            for (int j = 0; j < V; j++) v[u][j] = act_fwd(a[j] * v[u][j] + b[j], act);
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < V; j++) v[u][j] += r[u][j];
+            }
+            store_vec<T, V>(y + off, v[u]);
+            if (y_f32) store_vec<float, V>(y_f32 + off, v[u]);
+        }
     }
 }
 
@@ -185,17 +206,26 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
         }
         const long sample = (long)n * g.HW * g.C;
         const int pend = min(g.HW, (s + 1) * g.chunk);
-        for (int pix = s * g.chunk + slot; pix < pend; pix += slots) {
-            const long off = sample + (long)pix * g.C + cg * V;
-            float v[V], d[V];
-            load_vec<T, V>(x + off, v);
-            load_vec<T, V>(dy + off, d);
+        for (int pix0 = s * g.chunk + slot; pix0 < pend; pix0 += slots * kInPpt) {
+            float v[kInPpt][V], d[kInPpt][V];
 #pragma unroll
-            for (int j = 0; j < V; j++) {
-                const float xh = (v[j] - mean[j]) * rstd[j];
-                const float gg = d[j] * act_grad(sc[j] * xh + sh[j], act);
-                s1[j] += gg;
-                s2[j] += gg * xh;
+            for (int u = 0; u < kInPpt; u++) {
+                const int pix = pix0 + u * slots;
+                if (pix >= pend) continue;
+                const long off = sample + (long)pix * g.C + cg * V;
+                load_vec<T, V>(x + off, v[u]);
+                load_vec<T, V>(dy + off, d[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kInPpt; u++) {
+                if (pix0 + u * slots >= pend) continue;
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    const float xh = (v[u][j] - mean[j]) * rstd[j];
+                    const float gg = d[u][j] * act_grad(sc[j] * xh + sh[j], act);
+                    s1[j] += gg;
+                    s2[j] += gg * xh;
+                }
             }
         }
     }
@@ -241,18 +271,29 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
         sh[j] = shift[c];
     }
     const long sample = (long)n * g.HW * g.C;
-    for (int pix = blockIdx.x * slots + slot; pix < g.HW; pix += gridDim.x * slots) {
-        const long off = sample + (long)pix * g.C + cg * V;
-        float v[V], d[V];
-        load_vec<T, V>(x + off, v);
-        load_vec<T, V>(dy + off, d);
+    const int stride = gridDim.x * slots;
+    for (int pix0 = blockIdx.x * slots + slot; pix0 < g.HW; pix0 += stride * kInPpt) {
+        float v[kInPpt][V], d[kInPpt][V];
 #pragma unroll
-        for (int j = 0; j < V; j++) {
-            const float xh = (v[j] - mean[j]) * rstd[j];
-            const float gg = d[j] * act_grad(sc[j] * xh + sh[j], act);
-            v[j] = sc[j] * rstd[j] * (gg - m1[j] - xh * m2[j]);
+        for (int u = 0; u < kInPpt; u++) {
+            const int pix = pix0 + u * stride;
+            if (pix >= g.HW) continue;
+            const long off = sample + (long)pix * g.C + cg * V;
+            load_vec<T, V>(x + off, v[u]);
+            load_vec<T, V>(dy + off, d[u]);
         }
-        store_vec<T, V>(dx + off, v);
+#pragma unroll
+        for (int u = 0; u < kInPpt; u++) {
+            const int pix = pix0 + u * stride;
+            if (pix >= g.HW) continue;
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const float xh = (v[u][j] - mean[j]) * rstd[j];
+                const float gg = d[u][j] * act_grad(sc[j] * xh + sh[j], act);
+                v[u][j] = sc[j] * rstd[j] * (gg - m1[j] - xh * m2[j]);
+            }
+            store_vec<T, V>(dx + sample + (long)pix * g.C + cg * V, v[u]);
+        }
     }
 }
 
@@ -271,7 +312,7 @@ static InGeom make_geom(int n, int h, int w, int c) {
     g.N = n; g.HW = h * w; g.C = c;
     const int v = pick_v<T>(c) > 0 ? pick_v<T>(c) : 1;
     const int slots = 256 / (c / v);
-    long s = ((long)g.HW + slots * 8 - 1) / (slots * 8);  // ~8 pixels per thread
+    long s = ((long)g.HW + slots * kInPpt - 1) / (slots * kInPpt);  // one round of loads per thread
     if (s > kInMaxSplits) s = kInMaxSplits;
     if (s < 1) s = 1;
     g.S = (int)s;

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .vggnet import _SERIAL
 
 # (kind, cout, k, stride, act, residual-role)
 #   residual-role: 'a' = first conv of a residual block, 'b' = second (adds the block input)
@@ -146,7 +147,7 @@ class StylizerNet:
             # Gradient buffers: g, the skip gradient, dconv, dx -- and two more, so that a weight
             # gradient still reading an older dconv on the side stream does not hold up the chain.
             self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(6)]
-            self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+            self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'w' not in _SERIAL else None
             self._readers = {}  # data_ptr of a gradient buffer -> event after its last side-stream reader
         self.repack()
 

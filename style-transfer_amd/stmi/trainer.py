@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from .stylizer import StylizerNet
-from .vggnet import VggFeatures
+from .vggnet import VggFeatures, _SERIAL
 
 # block ranges (hi..lo) of the stylizer backward; one all-reduce bucket each
 BWD_SEGMENTS = [(15, 11), (10, 7), (6, 0)]
@@ -73,7 +73,7 @@ class StyleTrainer:
                                        group)
         self._graphs = None
         # the content targets only meet the rest of the step at the content loss
-        self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'c' not in _SERIAL else None
 
     # ------------------------------------------------------------- targets
     def set_style_image(self, style_f32):

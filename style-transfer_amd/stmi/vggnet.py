@@ -10,7 +10,13 @@ constants in the reference graph).
 """
 import torch
 
+import os
+
 from . import ops
+
+# tuning aid: STMI_SERIAL containing g / w / c keeps the Gram terms / weight gradients / content
+# targets on the main stream instead of a side stream
+_SERIAL = os.environ.get('STMI_SERIAL', '')
 
 LAYER_NAMES = [
     'conv1_1', 'relu1_1', 'conv1_2', 'relu1_2', 'pool1',
@@ -100,7 +106,7 @@ class VggReplica:
             self.tv_grad = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
         # Gram matrices and their loss terms hang off the conv chain as leaves: with kept
         # (dedicated) tap buffers they run on a side stream beside the following layers.
-        self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' else None
+        self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
         self._style_job = None
 
     def _buf(self, pool, shape, avoid):
