@@ -11,27 +11,11 @@
 // 16+4g..16+4g+3); it only has to agree between the two operands.
 // The pixel range is split over blocks; partial tiles are combined with fp32
 // atomic adds into a zeroed output.
-#include "common.hpp"
+#include "conv_wgrad.hpp"
 
 #include <stdlib.h>
 
 namespace stmi {
-
-struct WgradParams {
-    const void* x;
-    const void* dy;
-    float* dw;
-    int N, Hi, Wi, Ci;  // x
-    int Ho, Wo, Co;     // dy
-    int stride;
-    int ntaps, klen, cdiv;
-    long tap_out_stride;
-    long batch_out_stride;  // != 0: one output per sample (Gram)
-    int pix_per_block;
-    int splits;
-    float alpha;
-    Tap taps[kMaxTaps];
-};
 
 template <typename T> struct WgFrag;
 
@@ -317,6 +301,8 @@ int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int 
         int rc = zero_f32(dw, (long)kh * kw * ci * co, s);
         if (rc) return rc;
     }
+    int rc = STMI_OK;
+    if (try_launch_wgrad_glds(p, dtype, s, &rc)) return rc;
     if (dtype == STMI_BF16) return launch_wg_typed<bf16_t>(p, s);
     return launch_wg_typed<float>(p, s);
 }
@@ -336,6 +322,7 @@ int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype
     p.batch_out_stride = (long)c * c;
     int rc = zero_f32(g, (long)n * c * c, s);
     if (rc) return rc;
+    if (try_launch_wgrad_glds(p, dtype, s, &rc)) return rc;
     if (dtype == STMI_BF16) return launch_wg_typed<bf16_t>(p, s);
     return launch_wg_typed<float>(p, s);
 }

@@ -1,0 +1,314 @@
+// Pixel-reduction GEMM, LDS-DMA variant with producer / consumer waves (gfx950).
+//
+//   D[tap][e][co] += alpha * sum_pixels X[pixel @ tap][e] * DY[pixel][co]
+//
+// for operands whose channel counts are multiples of 128 bytes.  A block owns one
+// (tap, 128-byte channel chunk of X, 128-byte channel chunk of DY) tile and a slice of the
+// pixels.  Per step, 128 pixel rows of each operand (128 B each) go global -> LDS with
+// global_load_lds_dwordx4 through a 4-deep ring; rows outside the image or the slice come
+// from a page of zeros.  Eight producer waves only issue the DMA (each issue stalls its wave
+// for 60-180 cycles) and keep per-row pixel coordinates incrementally; four consumer waves
+// (one per SIMD beside two producers) read transposed fragments and run the MFMAs.  One
+// s_barrier per step hands a filled slot to the consumers and a drained one back.
+//
+// LDS rows are [pixel][channel chunk]; the 16-byte pieces of row r sit at position
+// p ^ (((r >> 1) & 3) << 1), which makes the ds_read_b64_tr_b16 fragment reads (4 rows x 32
+// bytes per 16 lanes) conflict-free.  The K order inside a 32-pixel group follows the
+// hardware transpose; it only has to agree between the two operands.
+//
+// The finished tile goes through LDS so that every wave adds whole 256-byte rows: float
+// atomics run at the memory side at about 1.3 TB/s, and only for contiguous rows.
+#include "conv_wgrad.hpp"
+
+#include <stdlib.h>
+
+namespace stmi {
+
+__device__ uint4 g_wg_zero_page[8];  // zero-initialised
+
+namespace {
+
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"  // host pass only: LDS pointers are 32-bit on the device
+template <typename T>
+__device__ __forceinline__ void glds16(const T* src, unsigned lds_byte_addr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_byte_addr, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 3) << 1; }
+
+// fragment of 16 channels (col0..) x one K group of pixels (row0..) from a swizzled tile
+template <typename T> struct TileFrag;
+
+template <> struct TileFrag<bf16_t> {
+    static constexpr int KPIX = 32;
+    static __device__ __forceinline__ bf16x8 load(const char* tile, int row0, int col0, int lane) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int r = row0 + 4 * g + q;  // r + 16 has the same swizzle
+        const int chunk = (col0 >> 3) + (pp >> 1);
+        const char* a0 = tile + r * 128 + ((chunk ^ row_swz(r)) << 4) + ((pp & 1) << 3);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * 128));
+        union {
+            s16x4 h[2];
+            bf16x8 f;
+        } u;
+        u.h[0] = lo;
+        u.h[1] = hi;
+        return u.f;
+    }
+};
+
+template <> struct TileFrag<float> {
+    static constexpr int KPIX = 16;
+    static __device__ __forceinline__ f32x4 load(const char* tile, int row0, int col0, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const int ch = col0 + i;
+        f32x4 f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int r = row0 + 4 * s + g;
+            f[s] = *reinterpret_cast<const float*>(tile + r * 128 + (((ch >> 2) ^ row_swz(r)) << 4) + ((ch & 3) << 2));
+        }
+        return f;
+    }
+};
+
+constexpr int kStepPix = 128;  // pixel rows per ring slot and operand
+constexpr int kRing = 4;
+constexpr int kProducers = 8;  // DMA-issuing waves: the fill rate of a CU scales with the waves that issue
+constexpr int kThreads = 64 * (4 + kProducers);
+
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams p) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int TILE = 8 * EPC;          // channels per 128-byte row: 64 bf16 / 32 f32
+    constexpr int TW = TILE / 32;          // 16-channel fragments per consumer wave and operand (2 x 2 waves)
+    constexpr int KPIX = TileFrag<T>::KPIX;
+    constexpr int OPER = kStepPix * 128;   // bytes per operand and slot
+    constexpr int SLOT = 2 * OPER;
+    constexpr int NI = 2 * (kStepPix / 8) / kProducers;  // DMA instructions per producer wave and step
+    static_assert(TW >= 1, "tile too small for 2 x 2 waves");
+    typedef typename Mma<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(128))) char lds[];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rtiles = p.klen / TILE, ctiles = p.Co / TILE;
+    // Blocks b and b+8 share an XCD.  Every XCD gets one contiguous run of (pixel slice, tile)
+    // pairs, tiles fastest: the blocks that read the same pixels then share one 4 MiB L2 and
+    // the two operands are fetched through it once instead of once per XCD.
+    const int ntiles = p.ntaps * rtiles * ctiles;
+    unsigned logical;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
+        logical = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    }
+    const int slice = logical / ntiles;
+    int t = logical - slice * ntiles;
+    const int ct = t % ctiles;
+    t /= ctiles;
+    const int rt = t % rtiles;
+    const int tap_i = t / rtiles;
+    const int r0 = rt * TILE, c0 = ct * TILE;
+    const bool batched = p.batch_out_stride != 0;
+    const int HWo = p.Ho * p.Wo;
+    int sample = 0, split = slice;
+    if (batched) {
+        sample = slice / p.splits;
+        split = slice - sample * p.splits;
+    }
+    const int pix_total = batched ? HWo : p.N * HWo;
+    const int pbeg = split * p.pix_per_block;
+    const int pend = min(pbeg + p.pix_per_block, pix_total);
+    const int nsteps = pbeg < pend ? (pend - pbeg + kStepPix - 1) / kStepPix : 0;
+
+    f32x4 acc[TW][TW];
+#pragma unroll
+    for (int a = 0; a < TW; a++)
+#pragma unroll
+        for (int b = 0; b < TW; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wave - 4, sub = lane >> 3, pos = lane & 7;
+        const Tap tap = p.taps[tap_i];
+        const T* x = (const T*)p.x;
+        const T* dy = (const T*)p.dy;
+        const T* zero_src = (const T*)(g_wg_zero_page + pos);
+        const int src_chunk = (pos ^ row_swz(sub)) * EPC;  // rows of a piece start at multiples of 8
+        constexpr int RPW = kStepPix / 8 / kProducers;     // 8-row pieces per wave, operand and step
+        // Per row slot: the pixel's index, its input coordinates under this tap and the element
+        // offsets of its two rows, all advanced by one step (128 pixels) with additions only
+        // (integer multiplies run at quarter rate and there are eight rows per lane and step).
+        int pix[RPW], iy[RPW], ix[RPW], oyv[RPW], xoff[RPW], doff[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+            const int pi = pbeg + (pw * RPW + j) * 8 + sub;
+            pix[j] = pi;
+            const int n = batched ? sample : pi / HWo;
+            const int rem = pi - (batched ? 0 : n * HWo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            oyv[j] = oy;
+            iy[j] = oy * p.stride + tap.dy;
+            ix[j] = ox * p.stride + tap.dx;
+            xoff[j] = ((n * p.Hi + iy[j]) * p.Wi + ix[j]) * p.Ci + r0 + src_chunk;
+            doff[j] = ((n * p.Ho + oy) * p.Wo + ox) * p.Co + c0 + src_chunk;
+        }
+        const int dq = kStepPix / p.Wo, dr = kStepPix - dq * p.Wo;
+        const int x_col = p.stride * p.Ci, x_row = p.stride * p.Wi * p.Ci;   // one output column / row, in x elements
+        const int x_adv = dr * x_col + dq * x_row;                           // dr columns and dq rows
+        const int x_wrap = x_row - p.Wo * x_col;                             // column wrap: back Wo columns, down a row
+        const int x_img = (p.Hi * p.Wi * p.Ci) - p.Ho * x_row;               // row wrap: back Ho rows, on to the next sample
+        const int d_adv = kStepPix * p.Co;                                   // dy rows are consecutive pixels
+        auto stage = [&](int slot) {
+            const unsigned xdst = lds_base + slot * SLOT + pw * RPW * 1024;
+            const unsigned ddst = xdst + OPER;
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                const bool live = pix[j] < pend;
+                const bool ok = live && (unsigned)iy[j] < (unsigned)p.Hi && (unsigned)ix[j] < (unsigned)p.Wi;
+                glds16(ok ? x + xoff[j] : zero_src, xdst + j * 1024);
+                glds16(live ? dy + doff[j] : zero_src, ddst + j * 1024);
+                // advance this row slot by one step
+                pix[j] += kStepPix;
+                doff[j] += d_adv;
+                ix[j] += dr * p.stride;
+                iy[j] += dq * p.stride;
+                oyv[j] += dq;
+                xoff[j] += x_adv;
+                if (ix[j] - tap.dx >= p.Wo * p.stride) {
+                    ix[j] -= p.Wo * p.stride;
+                    iy[j] += p.stride;
+                    oyv[j]++;
+                    xoff[j] += x_wrap;
+                }
+                if (!batched) {
+                    while (oyv[j] >= p.Ho) {
+                        oyv[j] -= p.Ho;
+                        iy[j] -= p.Ho * p.stride;
+                        xoff[j] += x_img;
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < kRing - 1; s++)
+            if (s < nsteps) stage(s);
+        for (int s = 0; s < nsteps; s++) {
+            // steps issued after s so far: min(nsteps - 1 - s, kRing - 2)
+            const int later = nsteps - 1 - s;
+            if (kRing >= 4 && later >= 2) wait_vmcnt<2 * NI>();
+            else if (later >= 1) wait_vmcnt<NI>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // slot of step s is filled; slot of step s-1 is drained
+            asm volatile("" ::: "memory");
+            if (s + kRing - 1 < nsteps) stage((s + kRing - 1) % kRing);
+        }
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const int wr = wave >> 1, wcn = wave & 1;
+        for (int s = 0; s < nsteps; s++) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* xs = lds + (s % kRing) * SLOT;
+            const char* ds = xs + OPER;
+#pragma unroll
+            for (int kk = 0; kk < kStepPix / KPIX; kk++) {
+                frag a[TW], b[TW];
+#pragma unroll
+                for (int i = 0; i < TW; i++) a[i] = TileFrag<T>::load(xs, kk * KPIX, (wr * TW + i) * 16, lane);
+#pragma unroll
+                for (int i = 0; i < TW; i++) b[i] = TileFrag<T>::load(ds, kk * KPIX, (wcn * TW + i) * 16, lane);
+#pragma unroll
+                for (int i = 0; i < TW; i++)
+#pragma unroll
+                    for (int j = 0; j < TW; j++) Mma<T>::mma(a[i], b[j], acc[i][j]);
+            }
+        }
+    }
+
+    // epilogue: tile -> LDS -> row-wise atomic adds
+    constexpr int LD = TILE + 4;
+    float* stage_f = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    if (wave < 4) {
+        const int wr = wave >> 1, wcn = wave & 1, g = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int a = 0; a < TW; a++)
+#pragma unroll
+            for (int b = 0; b < TW; b++)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    stage_f[((wr * TW + a) * 16 + 4 * g + u) * LD + (wcn * TW + b) * 16 + i] = acc[a][b][u];
+    }
+    __syncthreads();
+    if (nsteps == 0) return;
+    float* out = p.dw + (long)sample * p.batch_out_stride + (long)tap_i * p.tap_out_stride + (long)r0 * p.Co + c0;
+    const int col = tid % TILE;
+    for (int row = tid / TILE; row < TILE; row += kThreads / TILE)
+        atomicAdd(out + (long)row * p.Co + col, stage_f[row * LD + col] * p.alpha);
+}
+
+// ---------------------------------------------------------------------------
+static bool wg_eligible(const WgradParams& p, int dtype) {
+    const int tile = dtype == STMI_BF16 ? 64 : 32;
+    if (p.cdiv != 0 || p.klen != p.Ci || p.klen % tile != 0 || p.Co % tile != 0) return false;
+    if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
+    if ((((uintptr_t)p.x | (uintptr_t)p.dy) & 15) != 0) return false;
+    return true;
+}
+
+template <typename T>
+static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
+    constexpr int TILE = 128 / (int)sizeof(T);
+    constexpr size_t kLds = (size_t)kRing * 2 * kStepPix * 128;
+    static bool attr_set = false;  // idempotent; a racing second call is harmless
+    if (!attr_set) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)wgrad_glds_kernel<T>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
+                           "hipFuncSetAttribute(wgrad_glds_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    WgradParams p = p_in;
+    const bool batched = p.batch_out_stride != 0;
+    const long pix_total = batched ? (long)p.Ho * p.Wo : (long)p.N * p.Ho * p.Wo;
+    const long tiles = (long)p.ntaps * (p.klen / TILE) * (p.Co / TILE);
+    const long groups = tiles * (batched ? p.N : 1);
+    // one block per CU (128 KB of LDS); every extra slice of the pixels costs a tile of atomics
+    const char* tb = getenv("STMI_WG_BLOCKS");
+    const long target = tb ? atol(tb) : 256;
+    long splits = target / groups;
+    const long max_splits = (pix_total + 2 * kStepPix - 1) / (2 * kStepPix);  // at least two steps per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long ppb = (pix_total + splits - 1) / splits;
+    ppb = (ppb + kStepPix - 1) / kStepPix * kStepPix;
+    splits = (pix_total + ppb - 1) / ppb;
+    p.pix_per_block = (int)ppb;
+    p.splits = (int)splits;
+    const long blocks = tiles * splits * (batched ? p.N : 1);
+    STMI_REQUIRE(blocks < (1L << 31), "wgrad: grid too large");
+    dim3 grid((unsigned)blocks);
+    hipLaunchKernelGGL((wgrad_glds_kernel<T>), grid, dim3(kThreads), kLds, s, p);
+    STMI_LAUNCH_CHECK("wgrad_glds_kernel");
+    return STMI_OK;
+}
+
+bool try_launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s, int* rc) {
+    if (!wg_eligible(p, dtype) || getenv("STMI_NO_WG_GLDS")) return false;
+    *rc = dtype == STMI_BF16 ? launch_wg_glds<bf16_t>(p, s) : launch_wg_glds<float>(p, s);
+    return true;
+}
+
+}  // namespace stmi
