@@ -206,10 +206,11 @@ int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count,
  *                  STMI_PACK_DGRAD weights of the original kernel; dW = rows_wgrad_to_hwio(mode 1) of
  *                  conv2d_wgrad(x, r, [kh,1,ci,32])
  * pixels_to_rows   : rows[n,y,x,e] = x[n,y,x+dx0+e/c,e%c] for e < kw*c and an in-range column, else 0
- * rows_to_pixels_sum: y[n,yy,x,co] = sum_kx rows[n,yy,x+dx0+kx,kx*c+co] over in-range columns */
+ * rows_to_pixels_sum: y[n,yy,x,co] = sum_kx rows[n,yy,x+dx0+kx,kx*c+co] over in-range columns
+ *                    (+ addend[n,yy,x,co] when addend is not NULL) */
 int stmi_pixels_to_rows(const void* x, void* rows, int n, int h, int w, int c, int kw, int dx0,
                         int dtype, void* stream);
-int stmi_rows_to_pixels_sum(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0,
+int stmi_rows_to_pixels_sum(const void* rows, const void* addend, void* y, int n, int h, int w, int c, int kw, int dx0,
                             int dtype, void* stream);
 /* d fp32 is the [kh,1,32,co] (mode 0) or [kh,1,ci,32] (mode 1) gradient of the row-patch conv;
  * dw fp32 [kh,kw,ci,co] is the gradient of the original kernel, overwritten. */

@@ -45,7 +45,7 @@ int cast_impl(const void*, void*, long, int, int, hipStream_t);
 int clip_impl(float*, long, float, float, hipStream_t);
 int activation_impl(const void*, void*, long, int, int, hipStream_t);
 int pixels_to_rows_impl(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
-int rows_to_pixels_sum_impl(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int rows_to_pixels_sum_impl(const void*, const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int rows_wgrad_to_hwio_impl(const float*, float*, int, int, int, int, int, hipStream_t);
 int pool_fwd_impl(const void*, void*, int, int, int, int, int, hipStream_t);
 int pool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, hipStream_t);
@@ -298,12 +298,12 @@ int stmi_pixels_to_rows(const void* x, void* rows, int n, int h, int w, int c, i
     return pixels_to_rows_impl(x, rows, n, h, w, c, kw, dx0, dtype, S(stream));
 }
 
-int stmi_rows_to_pixels_sum(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
+int stmi_rows_to_pixels_sum(const void* rows, const void* addend, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
                             void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(rows && y && n >= 0 && h > 0 && w > 0 && c > 0 && kw > 0 && kw * c <= 32, "rows_to_pixels_sum: bad arguments");
     if (n == 0) return STMI_OK;
-    return rows_to_pixels_sum_impl(rows, y, n, h, w, c, kw, dx0, dtype, S(stream));
+    return rows_to_pixels_sum_impl(rows, addend, y, n, h, w, c, kw, dx0, dtype, S(stream));
 }
 
 int stmi_rows_wgrad_to_hwio(const float* d, float* dw, int kh, int kw, int ci, int co, int mode, void* stream) {

@@ -261,7 +261,7 @@ PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
     PackGeom g;
     if (mode == STMI_PACK_FWD_ROWOUT) {  // rows = (kx, co) pairs, one vertical tap per ky, K = ci
         g.rows = kw * co;
-        g.rows_pad = packed_rows(g.rows);
+        g.rows_pad = packed_rows(32);  // the row buffer is 32 wide whatever kw * co is
         g.row = false;
         g.ntaps = kh;
         g.klen = ci;

@@ -363,10 +363,10 @@ __global__ void pixels_to_rows_kernel(const T* __restrict__ x, T* __restrict__ r
     }
 }
 
-// y[n,yy,x,co] = sum_kx rows[n, yy, x + dx0 + kx, kx*c + co] over in-range columns
+// y[n,yy,x,co] = sum_kx rows[n, yy, x + dx0 + kx, kx*c + co] over in-range columns (+ addend)
 template <typename T>
-__global__ void rows_to_pixels_sum_kernel(const T* __restrict__ rows, T* __restrict__ y, int n, int h, int w, int c,
-                                          int kw, int dx0) {
+__global__ void rows_to_pixels_sum_kernel(const T* __restrict__ rows, const T* __restrict__ addend, T* __restrict__ y,
+                                          int n, int h, int w, int c, int kw, int dx0) {
     const long total = (long)n * h * w * c;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int co = (int)(i % c);
@@ -377,6 +377,7 @@ __global__ void rows_to_pixels_sum_kernel(const T* __restrict__ rows, T* __restr
             const int col = xx + dx0 + kx;
             if ((unsigned)col < (unsigned)w) acc += to_f32<T>(rows[(pix + dx0 + kx) * 32 + kx * c + co]);
         }
+        if (addend) acc += to_f32<T>(addend[i]);
         y[i] = from_f32<T>(acc);
     }
 }
@@ -407,13 +408,13 @@ int pixels_to_rows_impl(const void* x, void* rows, int n, int h, int w, int c, i
     return STMI_OK;
 }
 
-int rows_to_pixels_sum_impl(const void* rows, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
+int rows_to_pixels_sum_impl(const void* rows, const void* addend, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
                             hipStream_t s) {
     const dim3 grid(flat_blocks((long)n * h * w * c));
     if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)rows, (bf16_t*)y, n, h, w, c, kw, dx0);
+        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)rows, (const bf16_t*)addend, (bf16_t*)y, n, h, w, c, kw, dx0);
     else
-        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<float>, grid, dim3(256), 0, s, (const float*)rows, (float*)y, n, h, w, c, kw, dx0);
+        hipLaunchKernelGGL(rows_to_pixels_sum_kernel<float>, grid, dim3(256), 0, s, (const float*)rows, (const float*)addend, (float*)y, n, h, w, c, kw, dx0);
     STMI_LAUNCH_CHECK("rows_to_pixels_sum_kernel");
     return STMI_OK;
 }

@@ -48,7 +48,7 @@ SIGNATURES = {
     'stmi_adam_tf1': (_c_int, [_vp] * 4 + [_c_long] + [_c_float] * 5 + [_vp, _c_int, _vp]),
     'stmi_cast': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_pixels_to_rows': (_c_int, [_vp, _vp] + [_c_int] * 7 + [_vp]),
-    'stmi_rows_to_pixels_sum': (_c_int, [_vp, _vp] + [_c_int] * 7 + [_vp]),
+    'stmi_rows_to_pixels_sum': (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     'stmi_rows_wgrad_to_hwio': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_activation': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_clip': (_c_int, [_vp, _c_long, _c_float, _c_float, _vp]),

@@ -215,13 +215,16 @@ def pixels_to_rows(x, kw, dx0, out=None):
     return r
 
 
-def rows_to_pixels_sum(rows, c, kw, dx0, out=None):
+def rows_to_pixels_sum(rows, c, kw, dx0, out=None, addend=None):
     n, h, w, k = rows.shape
     assert k == 32
     _chk(rows, 'rows')
     oshape = (n, h, w, c)
+    if addend is not None:
+        _chk(addend, 'addend', rows.dtype, oshape)
     y = torch.empty(oshape, dtype=rows.dtype, device=rows.device) if out is None else _chk(out, 'out', rows.dtype, oshape)
-    _lib.call('stmi_rows_to_pixels_sum', rows.data_ptr(), y.data_ptr(), n, h, w, c, kw, dx0, _dt(rows), _stream())
+    _lib.call('stmi_rows_to_pixels_sum', rows.data_ptr(), _ptr(addend), y.data_ptr(), n, h, w, c, kw, dx0, _dt(rows),
+              _stream())
     return y
 
 

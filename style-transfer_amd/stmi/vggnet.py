@@ -56,6 +56,14 @@ class VggFeatures:
             L.bias = torch.as_tensor(b, dtype=torch.float32).reshape(-1).to(device).contiguous()
             L.wp_fwd = ops.pack_conv_weights(w, ops.PACK_FWD, dtype)
             L.wp_bwd = ops.pack_conv_weights(w, ops.PACK_DGRAD, dtype) if with_backward else None
+            # The RGB layer runs on row patches (3 x 3 x 3 -> three vertical taps over 32-wide rows;
+            # PACK_FWD of a < 8 channel kernel already is that layout).  Its backward-data is the
+            # forward convolution 64 -> 3 with the flipped, transposed kernel, rows on the output
+            # side; d(preprocess)/dx = 255/2 is folded into those weights.
+            L.rows = L.kshape[2] < 8 and L.kshape[0] * L.kshape[2] <= 32 and L.kshape[3] % 8 == 0
+            if L.rows and with_backward:
+                wt = (w.flip(0, 1).permute(0, 1, 3, 2) * (255.0 / 2.0)).contiguous()
+                L.wp_bwd_rows = ops.pack_conv_weights(wt, ops.PACK_FWD_ROWOUT, dtype)
             self.convs[name] = L
 
     def replica(self, batch, height, width, keep_for_backward=False, relu_taps=False):
@@ -72,6 +80,8 @@ class VggReplica:
         self.content_name = CONTENT_RELU_TAP if relu_taps else CONTENT_CONV_TAP
         assert not (keep and relu_taps), 'the backward pass is built for the pre-ReLU taps of the training path'
         self.x_pre = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+        self.rows_buf = torch.empty((batch, height, width, 32), dtype=dt, device=dev)   # row patches of x_pre
+        self.rows_gbuf = torch.empty((batch, height, width, 32), dtype=dt, device=dev) if keep else None
         self.act = {}      # name -> output buffer of that layer (post-ReLU for relu layers)
         self.pre = {}      # conv name -> pre-ReLU output where it is tapped
         self.shape = {}
@@ -134,6 +144,11 @@ class VggReplica:
             shape = self.shape[name]
             if name.startswith('conv'):
                 L = net.convs[name]
+                kshape = L.kshape
+                if i == 0 and L.rows:
+                    k = kshape[0]
+                    cur = ops.pixels_to_rows(cur, k, -((k - 1) // 2), out=self.rows_buf)
+                    kshape = (k, 1, 32, kshape[3])
                 has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
                 tap_pre = (not self.relu_taps) and want_grams and name in STYLE_CONV_TAPS
                 if has_relu:
@@ -145,9 +160,9 @@ class VggReplica:
                         y = self._buf(self._scratch, shape, (cur,))
                         pre = self._buf(self._scratch, shape, (cur, y)) if tap_pre else None
                     if pre is not None:
-                        ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=True, want_pre=True, out=y, out_pre=pre)
+                        ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, want_pre=True, out=y, out_pre=pre)
                     else:
-                        ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=True, out=y)
+                        ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, out=y)
                     self._tap(name, pre)
                     self._tap(rname, y)
                     cur = y
@@ -155,7 +170,7 @@ class VggReplica:
                     continue
                 # last layer of the truncated network: no ReLU follows
                 y = self.content if name == self.content_name else self._buf(self._scratch, shape, (cur,))
-                ops.conv2d_fwd(cur, L.wp_fwd, L.kshape, 1, bias=L.bias, relu=False, out=y)
+                ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=False, out=y)
                 self._tap(name, y)
                 cur = y
             elif name.startswith('pool'):
@@ -228,7 +243,13 @@ class VggReplica:
                 L = net.convs[name]
                 in_name = names[idx - 1] if idx > 0 else None
                 h, w = (self.shape[in_name][1], self.shape[in_name][2]) if in_name else (self.h, self.w)
-                if in_name is None:
+                if in_name is None and L.rows:
+                    # d(preprocess)/dx = 255/2 is in the weights; the TV gradient joins in the row sum
+                    k, ci = L.kshape[0], L.kshape[2]
+                    ops.conv2d_fwd(g, L.wp_bwd_rows, (k, 1, L.kshape[3], 32), 1, out=self.rows_gbuf)
+                    ops.rows_to_pixels_sum(self.rows_gbuf, ci, k, -((k - 1) // 2), out=self.d_image, addend=self.tv_grad)
+                    g = self.d_image
+                elif in_name is None:
                     # d(preprocess)/dx = 255/2; the TV gradient joins here
                     ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), alpha=255.0 / 2.0, addend=self.tv_grad,
                                      out=self.d_image)
