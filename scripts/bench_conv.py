@@ -14,7 +14,7 @@ LAYERS = [  # name, h, w, ci, co
     ('vgg3_1', 64, 64, 128, 256), ('vgg3_x', 64, 64, 256, 256), ('vgg4_1', 32, 32, 256, 512),
     ('vgg4_x', 32, 32, 512, 512), ('vgg5_x', 16, 16, 512, 512), ('res', 64, 64, 128, 128),
 ]
-cfgs = [None, 'v1', '0', '1', '2', '3', 'p64', 'p128']
+cfgs = [None, 'v1', '1', '3', 'p32', 'p64', 'p128']
 
 def run(x, wp, kshape, y, iters=20):
     """us per launch, launches replayed from a HIP graph so that host launch cost is not measured"""
@@ -49,7 +49,7 @@ for name, h, w, ci, co in LAYERS:
     for c in cfgs:
         for k in ('STMI_CONV_CFG', 'STMI_NO_GLDS', 'STMI_NO_PATCH', 'STMI_PATCH_CO'): os.environ.pop(k, None)
         if c == 'v1': os.environ['STMI_NO_GLDS'] = '1'; os.environ['STMI_NO_PATCH'] = '1'
-        elif c in ('p64', 'p128'): os.environ['STMI_PATCH_CO'] = c[1:]
+        elif c in ('p32', 'p64', 'p128'): os.environ['STMI_PATCH_CO'] = c[1:]
         elif c is not None: os.environ['STMI_CONV_CFG'] = c; os.environ['STMI_NO_PATCH'] = '1'
         t = run(x, wp, (3, 3, ci, co), y)
         if c == 'v1': ref = y.float().clone()

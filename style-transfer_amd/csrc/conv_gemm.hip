@@ -228,7 +228,6 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
         const int epc = dtype == STMI_BF16 ? 8 : 4;
         const uintptr_t ptrs = (uintptr_t)p.out | (uintptr_t)p.out_pre | (uintptr_t)p.mask | (uintptr_t)p.addend;
         p.row_store_ok = p.Co % epc == 0 && (ptrs & 15) == 0;
-        p.dbg = 0;
     }
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) {

@@ -22,7 +22,6 @@ struct ConvGemmParams {
     int relu;
     int row_store_ok;  // Co and the tensors' alignment allow whole-row 16-byte stores (set by the launcher)
     unsigned pt_div[3], pt_magic[3];  // patch kernel: channel tiles, tiles per row, tile rows per image (+ reciprocals)
-    int dbg;  // tuning aid of the patch kernel: bit 0 skips the fills, bit 1 the LDS reads and MFMAs
     Tap taps[kMaxTaps];
 };
 

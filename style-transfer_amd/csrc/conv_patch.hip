@@ -27,7 +27,6 @@ namespace stmi {
 
 __device__ uint4 g_patch_zero_page[8];  // zero-initialised: source of out-of-image rows
 
-__device__ long g_patch_times[4096 * 16];
 
 namespace {
 
@@ -111,8 +110,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     const unsigned patch_base = lds_base + NSW * W_SLOT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long ts[8];
-    ts[0] = wall_clock64();
     const int H = p.Hi, W = p.Wi, C = p.Ci;
 
     // tile of this block: blocks b and b+8 share an XCD, each XCD gets one contiguous run
@@ -164,9 +161,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 #pragma unroll
             for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], dst + j * 1024);
         };
-        ts[5] = wall_clock64();
         stage_weights(0, 0, 0);
-        ts[6] = wall_clock64();
         // patch rows this lane fetches in every chunk: element offset of the row's chunk, or -1.
         // Consecutive pieces are 8 patch rows apart: one division, then steps.
         int poff[kPatchPieces];
@@ -197,14 +192,12 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             const unsigned dst = patch_base + (chunk & 1) * P_BUF + (pw * kPatchPieces + i) * 1024;
             glds16(poff[i] >= 0 ? in + (poff[i] + chunk * BK) : zero_src, dst);
         };
-        ts[7] = wall_clock64();
         // The first patch is split with the consumer wave of the same index (idle until the
         // first barrier): issuing a piece costs the issuing wave 60-180 cycles.
 #pragma unroll
         for (int i = 0; i < kProloguePieces; i++) stage_patch_piece(i, 0);
 #pragma unroll
         for (int s = 1; s < NSW - 1; s++) stage_weights(s, 0, s);
-        ts[1] = wall_clock64();
 
         int slot = 0;  // ring slot of the current step
         auto chunk_body = [&](auto last_tag, int c) {
@@ -225,7 +218,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         };
         for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c);
         chunk_body(std::true_type{}, nchunks - 1);
-        ts[2] = ts[3] = wall_clock64();
     } else {
         // ------------------------------------------------------------------ consumer waves
         const int wc = wave >> 1, wpx = wave & 1;
@@ -291,7 +283,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 #pragma unroll
             for (int tp = 0; tp < TP; tp++) lds_landed(fb[HALF][tp]);
         };
-        ts[1] = wall_clock64();
 
         int slot = 0;
         unsigned baddr[TP];
@@ -304,7 +295,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
                 if (c == 0 && t == 0) wait_vmcnt<0>();  // own share of the first patch
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (c == 0 && t == 0) ts[2] = wall_clock64();
                 const Tap tap = p.taps[t];
                 const int shift = tap.dy * PWH + tap.dx;
                 const unsigned wbase = a_off + slot * W_SLOT;
@@ -323,7 +313,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             });
         }
         mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
-        ts[3] = wall_clock64();
     }
 
     // epilogue
@@ -343,12 +332,6 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
         });
     }
-    if ((p.dbg & 4) && blockIdx.x < 4096) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[4] = wall_clock64();
-        if (tid == 0 || tid == 256)
-            for (int i = 0; i < 8; i++) g_patch_times[(blockIdx.x * 2 + (tid >> 8)) * 8 + i] = ts[i];
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -359,7 +342,7 @@ static bool patch_eligible(const ConvGemmParams& p, int dtype) {
     if (p.ntaps != 9 || p.cdiv != 0 || p.klen <= 0 || p.klen % bk != 0 || p.klen != p.Ci) return false;
     if (p.w_batch_stride != 0 || p.in_stride != 1 || p.oys != 1 || p.oxs != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
     if (p.Hs != p.Hi || p.Ws != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi) return false;
-    if (p.co_pad % 64 != 0) return false;
+    if (p.co_pad % 32 != 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31)) return false;
     for (int t = 0; t < 9; t++)
         if (p.taps[t].dy < -1 || p.taps[t].dy > 1 || p.taps[t].dx < -1 || p.taps[t].dx > 1) return false;
@@ -373,15 +356,17 @@ static long patch_tiles(const ConvGemmParams& p, int blk_co) {
     return (long)p.N * ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw) * (p.co_pad / blk_co);
 }
 
-// 128 output channels per block when that still gives every CU a block.
-// STMI_PATCH_CO=64|128 forces the choice (tuning aid).
+// The widest channel tile (128, 64, 32) that still spreads the layer over the chip; the narrow
+// ones re-fetch the patch more often.  STMI_PATCH_CO=32|64|128 forces the choice (tuning aid).
 static int patch_blk_co(const ConvGemmParams& p) {
     const char* force = getenv("STMI_PATCH_CO");
     if (force) {
         const int c = atoi(force);
-        if ((c == 64 || c == 128) && p.co_pad % c == 0) return c;
+        if ((c == 32 || c == 64 || c == 128) && p.co_pad % c == 0) return c;
     }
-    return p.co_pad % 128 == 0 && patch_tiles(p, 128) >= 256 ? 128 : 64;
+    if (p.co_pad % 128 == 0 && patch_tiles(p, 128) >= 256) return 128;
+    if (p.co_pad % 64 == 0 && patch_tiles(p, 64) >= 64) return 64;
+    return 32;
 }
 
 template <typename T, int TC, int PW, int NSW>
@@ -398,8 +383,6 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     const long tiles = patch_tiles(p, 32 * TC);
     if (tiles <= 0) return STMI_OK;
     ConvGemmParams q = p;
-    const char* dbg = getenv("STMI_PATCH_DBG");
-    q.dbg = dbg ? atoi(dbg) : 0;
     {
         constexpr int PH = 128 / PW;
         const unsigned div[3] = {(unsigned)(p.co_pad / (32 * TC)), (unsigned)ceil_div(p.Wi, PW), (unsigned)ceil_div(p.Hi, PH)};
@@ -432,16 +415,14 @@ bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, in
         snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4>(stmi::ConvGemmParams)",
                  dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p));
     if (dtype == STMI_BF16)
-        *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s) : launch_patch_w<bf16_t, 2>(p, s);
+        *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s)
+                        : (co == 64 ? launch_patch_w<bf16_t, 2>(p, s) : launch_patch_w<bf16_t, 1>(p, s));
     else
-        *rc = co == 128 ? launch_patch_w<float, 4>(p, s) : launch_patch_w<float, 2>(p, s);
+        *rc = co == 128 ? launch_patch_w<float, 4>(p, s)
+                        : (co == 64 ? launch_patch_w<float, 2>(p, s) : launch_patch_w<float, 1>(p, s));
     return true;
 }
 
-int debug_patch_times(long* host, int n) {
-    return check_hip(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_patch_times), (size_t)n * sizeof(long)), "memcpy from symbol");
-}
 
 }  // namespace stmi
 
-extern "C" int stmi_debug_patch_times(long* host, int n) { return stmi::debug_patch_times(host, n); }
