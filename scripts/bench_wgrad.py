@@ -27,7 +27,7 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / (5 * n) * 1e3
 
 WG = [('res 3x3 128->128 @64', 64, 64, 128, 128, 3, 1), ('conv3 3x3s2 64->128 @128', 128, 128, 64, 128, 3, 2),
-      ('conv2 3x3s2 32->64 @256', 256, 256, 32, 64, 3, 2)]
+      ('conv2 3x3s2 32->64 @256', 256, 256, 32, 64, 3, 2), ('rows 9x1 32->32 @256', 256, 256, 32, 32, (9, 1), 1)]
 GR = [(256, 256, 64), (128, 128, 128), (64, 64, 256), (32, 32, 512), (16, 16, 512)]
 settings = [('old', {'STMI_NO_WG_GLDS': '1'}), ('new', {}), ('new/b128', {'STMI_WG_BLOCKS': '128'}), ('new/b512', {'STMI_WG_BLOCKS': '512'})]
 print('%-28s' % 'case' + ' '.join('%10s' % n for n, _ in settings) + '  (us; zero-fill kernel included)')
@@ -46,8 +46,9 @@ def sweep(name, fn, out):
 for name, h, w, ci, co, k, s in WG:
     x = torch.randn((B, h, w, ci), device=dev).to(dtype)
     dy = torch.randn((B, -(-h // s), -(-w // s), co), device=dev).to(dtype)
-    out = torch.empty((k, k, ci, co), device=dev)
-    sweep(name, lambda: ops.conv2d_wgrad(x, dy, (k, k, ci, co), s, out=out), out)
+    kh, kw = k if isinstance(k, tuple) else (k, k)
+    out = torch.empty((kh, kw, ci, co), device=dev)
+    sweep(name, lambda: ops.conv2d_wgrad(x, dy, (kh, kw, ci, co), s, out=out), out)
 for h, w, c in GR:
     f = torch.randn((B, h, w, c), device=dev).to(dtype)
     out = torch.empty((B, c, c), device=dev)

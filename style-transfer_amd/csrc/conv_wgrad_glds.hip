@@ -39,21 +39,25 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 3) << 1; }
+// chunk swizzle of a tile with RB-byte rows (conflict-free ds_read_b64_tr_b16 fragment reads)
+template <int RB>
+__device__ __forceinline__ int row_swz(int r) {
+    return RB == 128 ? ((r >> 1) & 3) << 1 : ((r >> 2) & 1) << 1;
+}
 
 // fragment of 16 channels (col0..) x one K group of pixels (row0..) from a swizzled tile
-template <typename T> struct TileFrag;
+template <typename T, int RB> struct TileFrag;
 
-template <> struct TileFrag<bf16_t> {
+template <int RB> struct TileFrag<bf16_t, RB> {
     static constexpr int KPIX = 32;
     static __device__ __forceinline__ bf16x8 load(const char* tile, int row0, int col0, int lane) {
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
         const int r = row0 + 4 * g + q;  // r + 16 has the same swizzle
         const int chunk = (col0 >> 3) + (pp >> 1);
-        const char* a0 = tile + r * 128 + ((chunk ^ row_swz(r)) << 4) + ((pp & 1) << 3);
+        const char* a0 = tile + r * RB + ((chunk ^ row_swz<RB>(r)) << 4) + ((pp & 1) << 3);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * 128));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * RB));
         union {
             s16x4 h[2];
             bf16x8 f;
@@ -64,7 +68,7 @@ template <> struct TileFrag<bf16_t> {
     }
 };
 
-template <> struct TileFrag<float> {
+template <int RB> struct TileFrag<float, RB> {
     static constexpr int KPIX = 16;
     static __device__ __forceinline__ f32x4 load(const char* tile, int row0, int col0, int lane) {
         const int g = lane >> 4, i = lane & 15;
@@ -73,7 +77,7 @@ template <> struct TileFrag<float> {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int r = row0 + 4 * s + g;
-            f[s] = *reinterpret_cast<const float*>(tile + r * 128 + (((ch >> 2) ^ row_swz(r)) << 4) + ((ch & 3) << 2));
+            f[s] = *reinterpret_cast<const float*>(tile + r * RB + (((ch >> 2) ^ row_swz<RB>(r)) << 4) + ((ch & 3) << 2));
         }
         return f;
     }
@@ -86,23 +90,26 @@ constexpr int kThreads = 64 * (4 + kProducers);
 
 }  // namespace
 
-template <typename T>
+// XB / DB: bytes per pixel row of the X / DY tile (128 or 64: 64 or 32 bf16 channels)
+template <typename T, int XB, int DB>
 __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams p) {
     constexpr int EPC = 16 / sizeof(T);
-    constexpr int TILE = 8 * EPC;          // channels per 128-byte row: 64 bf16 / 32 f32
-    constexpr int TW = TILE / 32;          // 16-channel fragments per consumer wave and operand (2 x 2 waves)
-    constexpr int KPIX = TileFrag<T>::KPIX;
-    constexpr int OPER = kStepPix * 128;   // bytes per operand and slot
-    constexpr int SLOT = 2 * OPER;
-    constexpr int NI = 2 * (kStepPix / 8) / kProducers;  // DMA instructions per producer wave and step
-    static_assert(TW >= 1, "tile too small for 2 x 2 waves");
+    constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);  // tile: TE x-channels by TD dy-channels
+    constexpr int TWX = TE / 32, TWD = TD / 32;  // 16-channel fragments per consumer wave (2 x 2 waves)
+    constexpr int KPIX = TileFrag<T, XB>::KPIX;
+    constexpr int XOPER = kStepPix * XB, SLOT = kStepPix * (XB + DB);  // bytes
+    constexpr int XRP = 1024 / XB, DRP = 1024 / DB;                    // rows per 1 KiB DMA piece
+    constexpr int XPW = kStepPix / XRP / kProducers, DPW = kStepPix / DRP / kProducers;  // pieces per producer and step
+    constexpr int NI = XPW + DPW;
+    static_assert(TWX >= 1 && TWD >= 1, "tile too small for 2 x 2 waves");
+    static_assert(XPW >= 1 && DPW >= 1, "fewer pieces than producer waves");
     typedef typename Mma<T>::frag frag;
 
     extern __shared__ __attribute__((aligned(128))) char lds[];
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rtiles = p.klen / TILE, ctiles = p.Co / TILE;
+    const int rtiles = p.klen / TE, ctiles = p.Co / TD;
     // Blocks b and b+8 share an XCD.  Every XCD gets one contiguous run of (pixel slice, tile)
     // pairs, tiles fastest: the blocks that read the same pixels then share one 4 MiB L2 and
     // the two operands are fetched through it once instead of once per XCD.
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
     t /= ctiles;
     const int rt = t % rtiles;
     const int tap_i = t / rtiles;
-    const int r0 = rt * TILE, c0 = ct * TILE;
+    const int r0 = rt * TE, c0 = ct * TD;
     const bool batched = p.batch_out_stride != 0;
     const int HWo = p.Ho * p.Wo;
     int sample = 0, split = slice;
@@ -132,56 +139,61 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
     const int pend = min(pbeg + p.pix_per_block, pix_total);
     const int nsteps = pbeg < pend ? (pend - pbeg + kStepPix - 1) / kStepPix : 0;
 
-    f32x4 acc[TW][TW];
+    f32x4 acc[TWX][TWD];
 #pragma unroll
-    for (int a = 0; a < TW; a++)
+    for (int a = 0; a < TWX; a++)
 #pragma unroll
-        for (int b = 0; b < TW; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TWD; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        const int pw = wave - 4, sub = lane >> 3, pos = lane & 7;
+        const int pw = wave - 4;
         const Tap tap = p.taps[tap_i];
         const T* x = (const T*)p.x;
         const T* dy = (const T*)p.dy;
-        const T* zero_src = (const T*)(g_wg_zero_page + pos);
-        const int src_chunk = (pos ^ row_swz(sub)) * EPC;  // rows of a piece start at multiples of 8
-        constexpr int RPW = kStepPix / 8 / kProducers;     // 8-row pieces per wave, operand and step
-        // Per row slot: the pixel's index, its input coordinates under this tap and the element
-        // offsets of its two rows, all advanced by one step (128 pixels) with additions only
-        // (integer multiplies run at quarter rate and there are eight rows per lane and step).
-        int pix[RPW], iy[RPW], ix[RPW], oyv[RPW], xoff[RPW], doff[RPW];
+        // lane -> (row of the piece, 16-byte position in the row); pieces start at multiples of
+        // their row count, so the swizzle only depends on the row inside the piece
+        const int xsub = lane / (XB / 16), xpos = lane % (XB / 16);
+        const int dsub = lane / (DB / 16), dpos = lane % (DB / 16);
+        const T* zero_src = (const T*)g_wg_zero_page;
+        // Per X row slot: the pixel's index, its input coordinates under this tap and the element
+        // offset of its row, advanced by one step (128 pixels) with additions only (integer
+        // multiplies run at quarter rate).  DY rows are consecutive pixels: an offset is enough.
+        int xpix[XPW], iy[XPW], ix[XPW], oyv[XPW], xoff[XPW];
 #pragma unroll
-        for (int j = 0; j < RPW; j++) {
-            const int pi = pbeg + (pw * RPW + j) * 8 + sub;
-            pix[j] = pi;
+        for (int j = 0; j < XPW; j++) {
+            const int pi = pbeg + (pw * XPW + j) * XRP + xsub;
+            xpix[j] = pi;
             const int n = batched ? sample : pi / HWo;
             const int rem = pi - (batched ? 0 : n * HWo);
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             oyv[j] = oy;
             iy[j] = oy * p.stride + tap.dy;
             ix[j] = ox * p.stride + tap.dx;
-            xoff[j] = ((n * p.Hi + iy[j]) * p.Wi + ix[j]) * p.Ci + r0 + src_chunk;
-            doff[j] = ((n * p.Ho + oy) * p.Wo + ox) * p.Co + c0 + src_chunk;
+            xoff[j] = ((n * p.Hi + iy[j]) * p.Wi + ix[j]) * p.Ci + r0 + (xpos ^ row_swz<XB>(xsub)) * EPC;
+        }
+        int dpix[DPW], doff[DPW];
+#pragma unroll
+        for (int j = 0; j < DPW; j++) {
+            const int pi = pbeg + (pw * DPW + j) * DRP + dsub;
+            dpix[j] = pi;
+            doff[j] = ((batched ? sample * HWo : 0) + pi) * p.Co + c0 + (dpos ^ row_swz<DB>(dsub)) * EPC;
         }
         const int dq = kStepPix / p.Wo, dr = kStepPix - dq * p.Wo;
         const int x_col = p.stride * p.Ci, x_row = p.stride * p.Wi * p.Ci;   // one output column / row, in x elements
         const int x_adv = dr * x_col + dq * x_row;                           // dr columns and dq rows
         const int x_wrap = x_row - p.Wo * x_col;                             // column wrap: back Wo columns, down a row
         const int x_img = (p.Hi * p.Wi * p.Ci) - p.Ho * x_row;               // row wrap: back Ho rows, on to the next sample
-        const int d_adv = kStepPix * p.Co;                                   // dy rows are consecutive pixels
+        const int d_adv = kStepPix * p.Co;
         auto stage = [&](int slot) {
-            const unsigned xdst = lds_base + slot * SLOT + pw * RPW * 1024;
-            const unsigned ddst = xdst + OPER;
+            const unsigned xdst = lds_base + slot * SLOT + pw * XPW * 1024;
+            const unsigned ddst = lds_base + slot * SLOT + XOPER + pw * DPW * 1024;
 #pragma unroll
-            for (int j = 0; j < RPW; j++) {
-                const bool live = pix[j] < pend;
-                const bool ok = live && (unsigned)iy[j] < (unsigned)p.Hi && (unsigned)ix[j] < (unsigned)p.Wi;
+            for (int j = 0; j < XPW; j++) {
+                const bool ok = xpix[j] < pend && (unsigned)iy[j] < (unsigned)p.Hi && (unsigned)ix[j] < (unsigned)p.Wi;
                 glds16(ok ? x + xoff[j] : zero_src, xdst + j * 1024);
-                glds16(live ? dy + doff[j] : zero_src, ddst + j * 1024);
                 // advance this row slot by one step
-                pix[j] += kStepPix;
-                doff[j] += d_adv;
+                xpix[j] += kStepPix;
                 ix[j] += dr * p.stride;
                 iy[j] += dq * p.stride;
                 oyv[j] += dq;
@@ -199,6 +211,12 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
                         xoff[j] += x_img;
                     }
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < DPW; j++) {
+                glds16(dpix[j] < pend ? dy + doff[j] : zero_src, ddst + j * 1024);
+                dpix[j] += kStepPix;
+                doff[j] += d_adv;
             }
         };
 #pragma unroll
@@ -221,60 +239,67 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const char* xs = lds + (s % kRing) * SLOT;
-            const char* ds = xs + OPER;
+            const char* ds = xs + XOPER;
 #pragma unroll
             for (int kk = 0; kk < kStepPix / KPIX; kk++) {
-                frag a[TW], b[TW];
+                frag a[TWX], b[TWD];
 #pragma unroll
-                for (int i = 0; i < TW; i++) a[i] = TileFrag<T>::load(xs, kk * KPIX, (wr * TW + i) * 16, lane);
+                for (int i = 0; i < TWX; i++) a[i] = TileFrag<T, XB>::load(xs, kk * KPIX, (wr * TWX + i) * 16, lane);
 #pragma unroll
-                for (int i = 0; i < TW; i++) b[i] = TileFrag<T>::load(ds, kk * KPIX, (wcn * TW + i) * 16, lane);
+                for (int i = 0; i < TWD; i++) b[i] = TileFrag<T, DB>::load(ds, kk * KPIX, (wcn * TWD + i) * 16, lane);
 #pragma unroll
-                for (int i = 0; i < TW; i++)
+                for (int i = 0; i < TWX; i++)
 #pragma unroll
-                    for (int j = 0; j < TW; j++) Mma<T>::mma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < TWD; j++) Mma<T>::mma(a[i], b[j], acc[i][j]);
             }
         }
     }
 
     // epilogue: tile -> LDS -> row-wise atomic adds
-    constexpr int LD = TILE + 4;
+    constexpr int LD = TD + 4;
     float* stage_f = reinterpret_cast<float*>(lds);
     __syncthreads();
     if (wave < 4) {
         const int wr = wave >> 1, wcn = wave & 1, g = lane >> 4, i = lane & 15;
 #pragma unroll
-        for (int a = 0; a < TW; a++)
+        for (int a = 0; a < TWX; a++)
 #pragma unroll
-            for (int b = 0; b < TW; b++)
+            for (int b = 0; b < TWD; b++)
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    stage_f[((wr * TW + a) * 16 + 4 * g + u) * LD + (wcn * TW + b) * 16 + i] = acc[a][b][u];
+                    stage_f[((wr * TWX + a) * 16 + 4 * g + u) * LD + (wcn * TWD + b) * 16 + i] = acc[a][b][u];
     }
     __syncthreads();
     if (nsteps == 0) return;
     float* out = p.dw + (long)sample * p.batch_out_stride + (long)tap_i * p.tap_out_stride + (long)r0 * p.Co + c0;
-    const int col = tid % TILE;
-    for (int row = tid / TILE; row < TILE; row += kThreads / TILE)
+    const int col = tid % TD;
+    for (int row = tid / TD; row < TE; row += kThreads / TD)
         atomicAdd(out + (long)row * p.Co + col, stage_f[row * LD + col] * p.alpha);
 }
 
 // ---------------------------------------------------------------------------
+// bytes per tile row for a channel count, 0 when the kernel cannot take it
+static int row_bytes(int channels, int dtype) {
+    const int es = dtype == STMI_BF16 ? 2 : 4;
+    if (channels * es % 128 == 0) return 128;
+    if (dtype == STMI_BF16 && channels * es % 64 == 0) return 64;  // 32 bf16 channels; f32 tiles would be too narrow
+    return 0;
+}
+
 static bool wg_eligible(const WgradParams& p, int dtype) {
-    const int tile = dtype == STMI_BF16 ? 64 : 32;
-    if (p.cdiv != 0 || p.klen != p.Ci || p.klen % tile != 0 || p.Co % tile != 0) return false;
+    if (p.cdiv != 0 || p.klen != p.Ci || row_bytes(p.Ci, dtype) == 0 || row_bytes(p.Co, dtype) == 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
     if ((((uintptr_t)p.x | (uintptr_t)p.dy) & 15) != 0) return false;
     return true;
 }
 
-template <typename T>
+template <typename T, int XB, int DB>
 static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
-    constexpr int TILE = 128 / (int)sizeof(T);
-    constexpr size_t kLds = (size_t)kRing * 2 * kStepPix * 128;
+    constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);
+    constexpr size_t kLds = (size_t)kRing * kStepPix * (XB + DB);
     static bool attr_set = false;  // idempotent; a racing second call is harmless
     if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)wgrad_glds_kernel<T>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)wgrad_glds_kernel<T, XB, DB>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(wgrad_glds_kernel)");
         if (rc) return rc;
@@ -283,11 +308,12 @@ static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
     WgradParams p = p_in;
     const bool batched = p.batch_out_stride != 0;
     const long pix_total = batched ? (long)p.Ho * p.Wo : (long)p.N * p.Ho * p.Wo;
-    const long tiles = (long)p.ntaps * (p.klen / TILE) * (p.Co / TILE);
+    const long tiles = (long)p.ntaps * (p.klen / TE) * (p.Co / TD);
     const long groups = tiles * (batched ? p.N : 1);
-    // one block per CU (128 KB of LDS); every extra slice of the pixels costs a tile of atomics
+    // about one block per CU for 64 x 64 tiles (every extra slice of the pixels costs a tile of
+    // atomics), two for the smaller tiles whose atomics are cheap and whose steps are short
     const char* tb = getenv("STMI_WG_BLOCKS");
-    const long target = tb ? atol(tb) : 256;
+    const long target = tb ? atol(tb) : (TE * TD >= 64 * 64 ? 256 : 512);
     long splits = target / groups;
     const long max_splits = (pix_total + 2 * kStepPix - 1) / (2 * kStepPix);  // at least two steps per block
     if (splits > max_splits) splits = max_splits;
@@ -300,14 +326,17 @@ static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
     const long blocks = tiles * splits * (batched ? p.N : 1);
     STMI_REQUIRE(blocks < (1L << 31), "wgrad: grid too large");
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL((wgrad_glds_kernel<T>), grid, dim3(kThreads), kLds, s, p);
+    hipLaunchKernelGGL((wgrad_glds_kernel<T, XB, DB>), grid, dim3(kThreads), kLds, s, p);
     STMI_LAUNCH_CHECK("wgrad_glds_kernel");
     return STMI_OK;
 }
 
 bool try_launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s, int* rc) {
     if (!wg_eligible(p, dtype) || getenv("STMI_NO_WG_GLDS")) return false;
-    *rc = dtype == STMI_BF16 ? launch_wg_glds<bf16_t>(p, s) : launch_wg_glds<float>(p, s);
+    const int xb = row_bytes(p.Ci, dtype), db = row_bytes(p.Co, dtype);
+    if (dtype != STMI_BF16) *rc = launch_wg_glds<float, 128, 128>(p, s);
+    else if (xb == 128) *rc = db == 128 ? launch_wg_glds<bf16_t, 128, 128>(p, s) : launch_wg_glds<bf16_t, 128, 64>(p, s);
+    else *rc = db == 128 ? launch_wg_glds<bf16_t, 64, 128>(p, s) : launch_wg_glds<bf16_t, 64, 64>(p, s);
     return true;
 }
 
