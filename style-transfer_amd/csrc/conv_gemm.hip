@@ -217,8 +217,9 @@ static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
 static thread_local char g_last_conv_kernel[192] = "";
 static const char* kV1Cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
 
-// Kernel choice: LDS-resident patch kernel for 3x3 stride-1 layers, LDS-DMA gather-GEMM for
-// the other layers with >= 128 bytes of K per tap, register-staged gather-GEMM for the rest.
+// Kernel choice: LDS-resident patch kernel for 3x3 stride-1 layers, producer / consumer LDS-DMA
+// gather-GEMM for the other layers with a multiple of 64 bytes of K per tap (the same-wave LDS-DMA
+// kernel stays behind it as a tuning reference), register-staged gather-GEMM for the rest.
 // The name of the instantiation launched is kept per thread for profiling front ends.
 int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     int rc = STMI_OK;
@@ -230,6 +231,7 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
         p.row_store_ok = p.Co % epc == 0 && (ptrs & 15) == 0;
     }
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+    if (try_launch_conv_gemm_pc(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) {
         snprintf(g_last_conv_kernel, sizeof(g_last_conv_kernel),
                  "void stmi::conv_gemm_glds_kernel<%s, %s>(stmi::ConvGemmParams)", tname, conv_gemm_glds_cfg_name(p, dtype));

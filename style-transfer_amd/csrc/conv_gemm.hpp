@@ -246,6 +246,11 @@ __device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, co
 bool try_launch_conv_gemm_glds(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc);
 const char* conv_gemm_glds_cfg_name(const ConvGemmParams& p, int dtype);
 
+// Producer / consumer gather-GEMM (conv_gemm_pc.hip) for K per tap a multiple of 64 bytes.
+// Returns true and launches when the problem fits it; name (optional) receives the kernel's
+// name as a profiler prints it.
+bool try_launch_conv_gemm_pc(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
+
 // 3x3 stride-1 kernel with the input patch resident in LDS (conv_patch.hip).  Returns true
 // and launches when the problem fits it; name (optional) receives the kernel's name as a
 // profiler prints it.
