@@ -267,3 +267,108 @@ def test_error_reporting(cuda):
         ops.conv2d_fwd(x, wp, (3, 3, 3, 8), 2)
     with pytest.raises(lib.StmiError, match='no CPU fallback'):
         ops.maxpool_fwd(torch.zeros((1, 2, 2, 8)))
+
+
+# ---------------------------------------------------------------- row patches
+def _pixels_to_rows_ref(x, kw, dx0):
+    """rows[n,y,x,e] = x[n,y,x+dx0+e//c,e%c] for e < kw*c and an in-range column, else 0 (include/stmi.h)"""
+    n, h, w, c = x.shape
+    rows = torch.zeros((n, h, w, 32), dtype=x.dtype)
+    for kx in range(kw):
+        for xx in range(w):
+            col = xx + dx0 + kx
+            if 0 <= col < w:
+                rows[:, :, xx, kx * c:(kx + 1) * c] = x[:, :, col, :]
+    return rows
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 5, 11, 3, 9, -4), (1, 4, 7, 3, 3, -1), (1, 3, 6, 3, 9, -4 + 0)], ids=str)
+def test_pixels_to_rows_and_back(cuda, dtype, case):
+    from stmi import ops
+    n, h, w, c, kw, dx0 = case
+    x = q(rnd((n, h, w, c), 11), dtype).to(dtype)
+    ref = _pixels_to_rows_ref(x, kw, dx0)
+    got = ops.pixels_to_rows(x.to(cuda), kw, dx0)
+    assert torch.equal(got.cpu(), ref)          # a copy: exact in both dtypes
+    # rows_to_pixels_sum: y[n,yy,x,co] = sum_kx rows[n,yy,x+dx0+kx,kx*c+co] over in-range columns (+ addend)
+    rows = q(rnd((n, h, w, 32), 12), dtype)
+    add = q(rnd((n, h, w, c), 13), dtype)
+    want = torch.zeros((n, h, w, c), dtype=torch.float64)
+    for kx in range(kw):
+        for xx in range(w):
+            col = xx + dx0 + kx
+            if 0 <= col < w:
+                want[:, :, xx, :] += rows[:, :, col, kx * c:(kx + 1) * c]
+    y = ops.rows_to_pixels_sum(rows.to(cuda, dtype), c, kw, dx0)
+    assert rel_err(y, want) <= TOL[dtype]
+    y2 = ops.rows_to_pixels_sum(rows.to(cuda, dtype), c, kw, dx0, addend=add.to(cuda, dtype))
+    assert rel_err(y2, want + add) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('k', [9, 3])
+def test_row_patch_convolutions_match_the_plain_ones(cuda, dtype, k):
+    """The three uses of row patches (include/stmi.h): conv c->co, conv ci->c forward and its
+    backward-data, and both weight gradients, against the oracle's ordinary convolution."""
+    from stmi import ops
+    n, h, w, c, cw = 2, 10, 13, 3, 32
+    pad = (k - 1) // 2
+    # c -> cw (rows on the input side)
+    x = rnd((n, h, w, c), 21)
+    wt = rnd((k, k, c, cw), 22, 1.0 / np.sqrt(k * k * c))
+    xq, wq = q(x, dtype).requires_grad_(), q(wt, dtype).requires_grad_()
+    y_ref = O.conv2d_same(xq, wq, 1)
+    dy = rnd(tuple(y_ref.shape), 23)
+    (gw_ref,) = torch.autograd.grad(y_ref, (wq,), q(dy, dtype))
+    rows = ops.pixels_to_rows(x.to(cuda, dtype), k, -pad)
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    y = ops.conv2d_fwd(rows, wp, (k, 1, 32, cw), 1)
+    assert rel_err(y, y_ref) <= TOL[dtype]
+    d = ops.conv2d_wgrad(rows, dy.to(cuda, dtype), (k, 1, 32, cw), 1)
+    gw = ops.rows_wgrad_to_hwio(d, (k, k, c, cw), 0)
+    assert rel_err(gw, gw_ref) <= TOL[dtype]
+    # cw -> c (rows on the output side)
+    x2 = rnd((n, h, w, cw), 24)
+    wt2 = rnd((k, k, cw, c), 25, 1.0 / np.sqrt(k * k * cw))
+    x2q, w2q = q(x2, dtype).requires_grad_(), q(wt2, dtype).requires_grad_()
+    y2_ref = O.conv2d_same(x2q, w2q, 1)
+    dy2 = rnd(tuple(y2_ref.shape), 26)
+    gx2_ref, gw2_ref = torch.autograd.grad(y2_ref, (x2q, w2q), q(dy2, dtype))
+    w2f = ops.pack_conv_weights(wt2.to(cuda, torch.float32), ops.PACK_FWD_ROWOUT, dtype)
+    w2b = ops.pack_conv_weights(wt2.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    t = ops.conv2d_fwd(x2.to(cuda, dtype), w2f, (k, 1, cw, 32), 1)
+    y2 = ops.rows_to_pixels_sum(t, c, k, -pad)
+    # the 32-wide intermediate is rounded to the compute dtype before the row sum
+    assert rel_err(y2, y2_ref) <= 2 * TOL[dtype]
+    r = ops.pixels_to_rows(dy2.to(cuda, dtype), k, pad - (k - 1))
+    dx2 = ops.conv2d_dgrad(r, w2b, (k, 1, cw, 32), 1, (h, w))
+    assert rel_err(dx2, gx2_ref) <= TOL[dtype]
+    d2 = ops.conv2d_wgrad(x2.to(cuda, dtype), r, (k, 1, cw, 32), 1)
+    gw2 = ops.rows_wgrad_to_hwio(d2, (k, k, cw, c), 1)
+    assert rel_err(gw2, gw2_ref) <= TOL[dtype]
+
+
+def test_pack_multi_matches_single_packs_and_kernel_name(cuda):
+    from stmi import ops
+    shapes = [((3, 3, 16, 32), ops.PACK_FWD), ((3, 3, 16, 32), ops.PACK_DGRAD), ((9, 9, 3, 32), ops.PACK_FWD),
+              ((9, 9, 32, 3), ops.PACK_FWD_ROWOUT), ((9, 9, 32, 3), ops.PACK_DGRAD)]
+    tensors = [rnd(s, 40 + i).float() for i, (s, _) in enumerate(shapes)]
+    flat = torch.cat([t.reshape(-1) for t in tensors]).to(cuda)
+    singles = [ops.pack_conv_weights(t.to(cuda), m, torch.bfloat16) for t, (_, m) in zip(tensors, shapes)]
+    table, src, dst = [], 0, 0
+    for t, (s, m), one in zip(tensors, shapes, singles):
+        table.append((src, dst, s, m))
+        src += t.numel()
+        dst += (one.numel() + 63) // 64 * 64
+    packed = torch.zeros(dst, dtype=torch.bfloat16, device=cuda)
+    ops.pack_conv_weights_multi(flat, packed, ops.make_pack_table(table))
+    for (_, d, _, _), one in zip(table, singles):
+        assert torch.equal(packed[d:d + one.numel()], one)
+    # the library reports the kernel it launched last (used by the bench's roofline leg)
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=cuda)
+    wp = ops.pack_conv_weights(torch.zeros((3, 3, 64, 64), device=cuda), ops.PACK_FWD, torch.bfloat16)
+    ops.conv2d_fwd(x, wp, (3, 3, 64, 64), 1)
+    assert 'conv_patch_kernel<__bf16' in ops.last_conv_kernel()
+    ops.conv2d_fwd(x, wp, (3, 3, 64, 64), 2)
+    assert 'conv_gemm_pc_kernel<__bf16' in ops.last_conv_kernel()
