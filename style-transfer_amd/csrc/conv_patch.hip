@@ -394,7 +394,10 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
         }
     }
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW>), dim3((unsigned)tiles), dim3(512), kLds, s, q);
+    // a layer with a single channel chunk never touches the second patch buffer
+    const int bk = 128 / (int)sizeof(T);
+    const size_t lds_bytes = p.klen == bk ? kLds - 4 * kPatchPieces * 8 * 128 : kLds;
+    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW>), dim3((unsigned)tiles), dim3(512), lds_bytes, s, q);
     STMI_LAUNCH_CHECK("conv_patch_kernel");
     return STMI_OK;
 }
