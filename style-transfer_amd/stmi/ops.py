@@ -44,9 +44,9 @@ def same_out(size, stride):
     return -(-size // stride)
 
 
-# Optional per-launch timing for bench.py's roofline leg: when PROFILE is a list, every
-# stride-1 conv forward / backward-data launch appends (kernel name, algorithmic flops,
-# start event, end event).  The events are recorded on the stream the kernel is launched on.
+# Optional launch log for bench.py's roofline leg: when PROFILE is a list, every stride-1 conv
+# forward / backward-data call appends (name of the kernel the library launched, algorithmic
+# flops, a closure that launches the same call again on the then-current stream).
 PROFILE = None
 
 
@@ -58,22 +58,12 @@ def last_conv_kernel():
     return buf.value.decode()
 
 
-class _Timed:
-    def __init__(self, out_channels, out_pixels, k_channels, taps, dtype_code, stride):
-        self.on = PROFILE is not None and stride == 1
-        if self.on:
-            self.flops = 2.0 * out_channels * out_pixels * k_channels * taps
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-
-    def __enter__(self):
-        if self.on:
-            self.e0.record(torch.cuda.current_stream())
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((last_conv_kernel(), self.flops, self.e0, self.e1))
+def _conv_call(entry, args, out_channels, out_pixels, k_channels, taps, stride):
+    """Launches a conv entry point (the stream is appended to args) and logs it when asked to."""
+    _lib.call(entry, *args, _stream())
+    if PROFILE is not None and stride == 1:
+        PROFILE.append((last_conv_kernel(), 2.0 * out_channels * out_pixels * k_channels * taps,
+                        lambda: _lib.call(entry, *args, _stream())))
 
 
 # ---------------------------------------------------------------- weights
@@ -125,9 +115,9 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
         pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', x.dtype, oshape)
     if bias is not None:
         _chk(bias, 'bias', torch.float32, (co,))
-    with _Timed(co, n * oshape[1] * oshape[2], ci, kh * kw, _dt(x), stride):
-        _lib.call('stmi_conv2d_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
-                  n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x), _stream())
+    _conv_call('stmi_conv2d_nhwc_fwd', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
+                                        n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x)),
+               co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
     return (y, pre) if want_pre else y
 
 
@@ -143,9 +133,9 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
     for t, nm in ((relu_mask, 'relu_mask'), (addend, 'addend')):
         if t is not None:
             _chk(t, nm, dy.dtype, oshape)
-    with _Timed(ci, n * h * w, co, kh * kw, _dt(dy), stride):
-        _lib.call('stmi_conv2d_nhwc_dgrad', dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
-                  _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy), _stream())
+    _conv_call('stmi_conv2d_nhwc_dgrad', (dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
+                                          _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy)),
+               ci, n * h * w, co, kh * kw, stride)
     return dx
 
 
