@@ -85,6 +85,20 @@ def timed_steps(step_fn, steps, warmup, world, device):
     return max_over_ranks(time.perf_counter() - t0, world, device)
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the committed counter passes
+    (profiles/r01_pmc_traffic.json, written by scripts/make_pmc.sh + scripts/pmc_summary.py: counters
+    cannot be collected from inside this process); None when the kernel is not listed there."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            entry = json.load(f)['kernels'].get(kernel_name)
+    except (OSError, ValueError, KeyError):
+        return None
+    return None if entry is None else entry['bytes_per_launch']
+
+
 def roofline_train(trainer, dtype_name):
     """Roofline object of the convolution kernel instantiation with the largest total time.
 
@@ -134,7 +148,8 @@ def roofline_train(trainer, dtype_name):
     total = sum(v[1] for v in acc.values())
     return {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-        'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': name,
+        'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name), 'traffic_unit': 'bytes per launch',
+        'kernel': name,
         'launches_per_step': launches, 'avg_launch_us': round(secs / launches * 1e6, 2),
         'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
         'all_conv_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'launches_per_step': v[2],
