@@ -13,7 +13,7 @@ def load(d):
     return agg
 
 def demangled(name):
-    m = re.match(r'_ZN4stmi\d+(\w+?)I(DF16b|f)((?:Li\d+E)+)EEvNS_\d+\w+E', name)
+    m = re.match(r'_ZN4stmi\d+(\w+?)I(DF16b|f)((?:Li\d+E)+)(?:Lb[01]E)?EEvNS_\d+\w+E', name)
     if not m:
         return name
     args = ', '.join(re.findall(r'Li(\d+)E', m.group(3)))

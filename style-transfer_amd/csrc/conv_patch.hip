@@ -88,7 +88,10 @@ constexpr int in_flight_ok(int nsw, int ni_w, bool last, int t) {
 
 }  // namespace
 
-template <typename T, int TC, int PW, int NSW>
+// ONE: the layer has a single channel chunk (Cin * sizeof(T) == 128): every instruction runs once,
+// i.e. misses the instruction cache once, so that instantiation keeps its code small (rolled tap
+// loop in the MFMA waves, no next-patch logic in the DMA waves).
+template <typename T, int TC, int PW, int NSW, bool ONE>
 __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;       // channels per chunk (128 bytes)
@@ -216,7 +219,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
                 slot = slot + 1 == NSW ? 0 : slot + 1;
             });
         };
-        for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c);
+        if constexpr (!ONE) {
+            for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c);
+        }
         chunk_body(std::true_type{}, nchunks - 1);
     } else {
         // ------------------------------------------------------------------ consumer waves
@@ -288,29 +293,35 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         unsigned baddr[TP];
 #pragma unroll
         for (int tp = 0; tp < TP; tp++) baddr[tp] = 0;
-        for (int c = 0; c < nchunks; c++) {
-            const unsigned pbuf = patch_base + (c & 1) * P_BUF;
-            static_for<0, 9>([&](auto t_tag) {
-                constexpr int t = decltype(t_tag)::value;
-                if (c == 0 && t == 0) wait_vmcnt<0>();  // own share of the first patch
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const Tap tap = p.taps[t];
-                const int shift = tap.dy * PWH + tap.dx;
-                const unsigned wbase = a_off + slot * W_SLOT;
+        auto tap_step = [&](int c, int t, unsigned pbuf) {
+            if (c == 0 && t == 0) wait_vmcnt<0>();  // own share of the first patch
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const Tap tap = p.taps[t];
+            const int shift = tap.dy * PWH + tap.dx;
+            const unsigned wbase = a_off + slot * W_SLOT;
 #pragma unroll
-                for (int tp = 0; tp < TP; tp++) {
-                    const int pr = pr_c[tp] + shift;
-                    baddr[tp] = pbuf + pr * 128 + ((g ^ (pr & 7)) << 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // second half of the previous step under the reads of this step's first half
-                mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);
-                landed(std::integral_constant<int, 0>{});
-                mma_and_read(std::integral_constant<int, 0>{}, wbase, baddr, true);
-                landed(std::integral_constant<int, 1>{});  // every read of the step is back before the next barrier
-                slot = slot + 1 == NSW ? 0 : slot + 1;
-            });
+            for (int tp = 0; tp < TP; tp++) {
+                const int pr = pr_c[tp] + shift;
+                baddr[tp] = pbuf + pr * 128 + ((g ^ (pr & 7)) << 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // second half of the previous step under the reads of this step's first half
+            mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);
+            landed(std::integral_constant<int, 0>{});
+            mma_and_read(std::integral_constant<int, 0>{}, wbase, baddr, true);
+            landed(std::integral_constant<int, 1>{});  // every read of the step is back before the next barrier
+            slot = slot + 1 == NSW ? 0 : slot + 1;
+        };
+        if constexpr (ONE) {
+#pragma nounroll
+            for (int t = 0; t < 9; t++) tap_step(0, t, patch_base);
+        } else {
+            // Unrolled, the per-tap fragment addresses are loop invariants of the chunk loop.
+            for (int c = 0; c < nchunks; c++) {
+                const unsigned pbuf = patch_base + (c & 1) * P_BUF;
+                static_for<0, 9>([&](auto t_tag) { tap_step(c, decltype(t_tag)::value, pbuf); });
+            }
         }
         mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
     }
@@ -369,12 +380,12 @@ static int patch_blk_co(const ConvGemmParams& p) {
     return 32;
 }
 
-template <typename T, int TC, int PW, int NSW>
+template <typename T, int TC, int PW, int NSW, bool ONE>
 static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * 4 * kPatchPieces * 8 * 128;
     static bool attr_set = false;  // idempotent; a racing second call is harmless
     if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_kernel<T, TC, PW, NSW>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_kernel<T, TC, PW, NSW, ONE>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_patch_kernel)");
         if (rc) return rc;
@@ -395,19 +406,19 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     }
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
     // a layer with a single channel chunk never touches the second patch buffer
-    const int bk = 128 / (int)sizeof(T);
-    const size_t lds_bytes = p.klen == bk ? kLds - 4 * kPatchPieces * 8 * 128 : kLds;
-    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW>), dim3((unsigned)tiles), dim3(512), lds_bytes, s, q);
+    const size_t lds_bytes = ONE ? kLds - 4 * kPatchPieces * 8 * 128 : kLds;
+    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW, ONE>), dim3((unsigned)tiles), dim3(512), lds_bytes, s, q);
     STMI_LAUNCH_CHECK("conv_patch_kernel");
     return STMI_OK;
 }
 
 template <typename T, int TC>
 static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
+    const bool one = p.klen == 128 / (int)sizeof(T);
     switch (patch_width(p)) {
-        case 64: return launch_patch<T, TC, 64, 4>(p, s);
-        case 32: return launch_patch<T, TC, 32, 4>(p, s);
-        default: return launch_patch<T, TC, 16, 4>(p, s);
+        case 64: return one ? launch_patch<T, TC, 64, 4, true>(p, s) : launch_patch<T, TC, 64, 4, false>(p, s);
+        case 32: return one ? launch_patch<T, TC, 32, 4, true>(p, s) : launch_patch<T, TC, 32, 4, false>(p, s);
+        default: return one ? launch_patch<T, TC, 16, 4, true>(p, s) : launch_patch<T, TC, 16, 4, false>(p, s);
     }
 }
 
@@ -415,8 +426,9 @@ bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, in
     if (!patch_eligible(p, dtype) || getenv("STMI_NO_PATCH")) return false;
     const int co = patch_blk_co(p);
     if (name)
-        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4>(stmi::ConvGemmParams)",
-                 dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p));
+        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
+                 dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),
+                 p.klen == (dtype == STMI_BF16 ? 64 : 32) ? "true" : "false");
     if (dtype == STMI_BF16)
         *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s)
                         : (co == 64 ? launch_patch_w<bf16_t, 2>(p, s) : launch_patch_w<bf16_t, 1>(p, s));
