@@ -369,13 +369,15 @@ static long patch_tiles(const ConvGemmParams& p, int blk_co) {
 
 // The widest channel tile (128, 64, 32) that still spreads the layer over the chip; the narrow
 // ones re-fetch the patch more often.  STMI_PATCH_CO=32|64|128 forces the choice (tuning aid).
-static int patch_blk_co(const ConvGemmParams& p) {
+static int patch_blk_co(const ConvGemmParams& p, int dtype) {
     const char* force = getenv("STMI_PATCH_CO");
     if (force) {
         const int c = atoi(force);
         if ((c == 32 || c == 64 || c == 128) && p.co_pad % c == 0) return c;
     }
-    if (p.co_pad % 128 == 0 && patch_tiles(p, 128) >= 256) return 128;
+    // single-chunk layers are all prologue and epilogue: more, smaller blocks hide more of it
+    const bool one_chunk = p.klen == (dtype == STMI_BF16 ? 64 : 32);
+    if (p.co_pad % 128 == 0 && patch_tiles(p, 128) >= 256 && !one_chunk) return 128;
     if (p.co_pad % 64 == 0 && patch_tiles(p, 64) >= 64) return 64;
     return 32;
 }
@@ -424,7 +426,7 @@ static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
 
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     if (!patch_eligible(p, dtype) || getenv("STMI_NO_PATCH")) return false;
-    const int co = patch_blk_co(p);
+    const int co = patch_blk_co(p, dtype);
     if (name)
         snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
                  dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),
