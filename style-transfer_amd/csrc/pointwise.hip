@@ -223,19 +223,21 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
                                                        float grad_scale, int n, int c, int rows_pad, int kpad) {
     __shared__ float red[4];
     float acc = 0.f;
-    const long total = (long)n * rows_pad * kpad;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int col = (int)(i % kpad);
-        const int row = (int)((i / kpad) % rows_pad);
-        const int b = (int)(i / ((long)kpad * rows_pad));
-        float v = 0.f;
-        if (row < c && col < c) {
-            const float d = g[((long)b * c + row) * c + col] - target[(long)row * c + col];
-            const float dt = g[((long)b * c + col) * c + row] - target[(long)col * c + row];
-            acc += d * d;
-            v = grad_scale * 0.5f * (d + dt);  // (dG + dG^T)/2: exact also for a non-symmetric target
+    // a block walks whole packed rows: 32-bit index arithmetic, no per-element division
+    for (int br = blockIdx.x; br < n * rows_pad; br += gridDim.x) {
+        const int b = br / rows_pad, row = br - b * rows_pad;
+        const float* gb = g + (long)b * c * c;
+        T* so = sout + (long)br * kpad;
+        for (int col = threadIdx.x; col < kpad; col += 256) {
+            float v = 0.f;
+            if (row < c && col < c) {
+                const float d = gb[row * c + col] - target[row * c + col];
+                const float dt = gb[col * c + row] - target[col * c + row];
+                acc += d * d;
+                v = grad_scale * 0.5f * (d + dt);  // (dG + dG^T)/2: exact also for a non-symmetric target
+            }
+            so[col] = from_f32<T>(v);
         }
-        sout[i] = from_f32<T>(v);
     }
     const float tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
 int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, float loss_scale, float grad_scale,
                   int n, int c, int dtype, hipStream_t s) {
     const int rows_pad = packed_rows(c), kpad = round_up(c, 32);
-    const dim3 grid(reduce_blocks((long)n * rows_pad * kpad));
+    const dim3 grid(n * rows_pad < 256 ? n * rows_pad : 256);  // few blocks: one same-address atomic each
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(gram_mse_kernel<bf16_t>, grid, dim3(256), 0, s, g, target, (bf16_t*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
     else
@@ -260,20 +262,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, T* __restrict__ grad, float* loss,
                                                  float wx, float wy, int n, int h, int w, int c) {
     __shared__ float red[4];
-    const long total = (long)n * h * w * c;
-    const long rowst = (long)w * c;
+    // a block walks whole image rows: 32-bit index arithmetic, one division per element
+    const int rowst = w * c, rows = n * h;
     float acc = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pix = i / c;
-        const int x = (int)(pix % w);
-        const int y = (int)((pix / w) % h);
-        const float v = img[i];
-        float gsum = 0.f;
-        if (x + 1 < w) { const float d = img[i + c] - v; acc += wx * d * d; gsum -= 2.f * wx * d; }
-        if (x > 0) { const float d = v - img[i - c]; gsum += 2.f * wx * d; }
-        if (y + 1 < h) { const float d = img[i + rowst] - v; acc += wy * d * d; gsum -= 2.f * wy * d; }
-        if (y > 0) { const float d = v - img[i - rowst]; gsum += 2.f * wy * d; }
-        grad[i] = from_f32<T>(gsum);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int y = row % h;
+        const float* r = img + (long)row * rowst;
+        T* gr = grad + (long)row * rowst;
+        for (int j = threadIdx.x; j < rowst; j += 256) {
+            const int x = j / c;
+            const float v = r[j];
+            float gsum = 0.f;
+            if (x + 1 < w) { const float d = r[j + c] - v; acc += wx * d * d; gsum -= 2.f * wx * d; }
+            if (x > 0) { const float d = v - r[j - c]; gsum += 2.f * wx * d; }
+            if (y + 1 < h) { const float d = r[j + rowst] - v; acc += wy * d * d; gsum -= 2.f * wy * d; }
+            if (y > 0) { const float d = v - r[j - rowst]; gsum += 2.f * wy * d; }
+            gr[j] = from_f32<T>(gsum);
+        }
     }
     const float tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) atomicAdd(loss, tot);
@@ -284,7 +289,7 @@ int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int 
     // reduce_mean over [n,h,w-1,c] and [n,h-1,w,c]; a 1-wide axis gives an empty mean (NaN in TF): treated as 0 here
     const float wx = w > 1 ? weight / ((float)n * h * (w - 1) * c) : 0.f;
     const float wy = h > 1 ? weight / ((float)n * (h - 1) * w * c) : 0.f;
-    const dim3 grid(reduce_blocks((long)n * h * w * c));
+    const dim3 grid(n * h < 256 ? n * h : 256);  // few blocks: each ends with one atomic on the same address
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, n, h, w, c);
     else
