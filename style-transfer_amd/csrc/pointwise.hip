@@ -82,10 +82,10 @@ int clip_impl(float* x, long count, float lo, float hi, hipStream_t s) {
 template <typename T, int V>
 __global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c) {
     const int ho = (h + 1) / 2, wo = (w + 1) / 2, cg = c / V;
-    const long total = (long)n * ho * wo * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)n * ho * wo * cg;  // < 2^31, checked by the launcher: 32-bit divisions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
-        long r = i / cg;
+        unsigned r = i / cg;
         const int ox = (int)(r % wo); r /= wo;
         const int oy = (int)(r % ho);
         const int b = (int)(r / ho);
@@ -112,10 +112,10 @@ template <typename T, int V>
 __global__ void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int n, int h,
                                 int w, int c) {
     const int ho = (h + 1) / 2, wo = (w + 1) / 2, cg = c / V;
-    const long total = (long)n * ho * wo * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)n * ho * wo * cg;  // < 2^31, checked by the launcher: 32-bit divisions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
-        long r = i / cg;
+        unsigned r = i / cg;
         const int ox = (int)(r % wo); r /= wo;
         const int oy = (int)(r % ho);
         const int b = (int)(r / ho);
@@ -156,6 +156,7 @@ template <typename T>
 static int pool_typed(bool bwd, const void* x, const void* dy, void* out, int n, int h, int w, int c, hipStream_t s) {
     constexpr int VMAX = 16 / (int)sizeof(T);
     const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    STMI_REQUIRE((long)n * ho * wo * c < (1L << 31), "max pool: more than 2^31 work items");
     if (c % VMAX == 0) {
         const dim3 grid(flat_blocks((long)n * ho * wo * (c / VMAX)));
         if (bwd) hipLaunchKernelGGL((pool_bwd_kernel<T, VMAX>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, n, h, w, c);
@@ -344,12 +345,12 @@ namespace stmi {
 template <typename T>
 __global__ void pixels_to_rows_kernel(const T* __restrict__ x, T* __restrict__ rows, int n, int h, int w, int c,
                                       int kw, int dx0) {
-    const long total = (long)n * h * w * 4;  // 4 chunks of 8 elements per pixel
+    const unsigned total = (unsigned)n * h * w * 4;  // 4 chunks of 8 elements per pixel; < 2^31 (launcher)
     const int klen = kw * c;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int chunk = (int)(i & 3);
         const long pix = i >> 2;
-        const int xx = (int)(pix % w);
+        const int xx = (int)((i >> 2) % (unsigned)w);
         const long rowbase = (pix - xx) * c;  // element offset of column 0 of this image row
         float v[8];
 #pragma unroll
@@ -372,11 +373,11 @@ __global__ void pixels_to_rows_kernel(const T* __restrict__ x, T* __restrict__ r
 template <typename T>
 __global__ void rows_to_pixels_sum_kernel(const T* __restrict__ rows, const T* __restrict__ addend, T* __restrict__ y,
                                           int n, int h, int w, int c, int kw, int dx0) {
-    const long total = (long)n * h * w * c;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % c);
-        const long pix = i / c;
-        const int xx = (int)(pix % w);
+    const unsigned total = (unsigned)n * h * w * c;  // < 2^31 (launcher): 32-bit divisions
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = (int)(i % (unsigned)c);
+        const long pix = i / (unsigned)c;
+        const int xx = (int)((i / (unsigned)c) % (unsigned)w);
         float acc = 0.f;
         for (int kx = 0; kx < kw; kx++) {
             const int col = xx + dx0 + kx;
@@ -404,6 +405,7 @@ __global__ void rows_wgrad_to_hwio_kernel(const float* __restrict__ d, float* __
 
 int pixels_to_rows_impl(const void* x, void* rows, int n, int h, int w, int c, int kw, int dx0, int dtype,
                         hipStream_t s) {
+    STMI_REQUIRE((long)n * h * w * 4 < (1L << 31), "pixels_to_rows: more than 2^31 work items");
     const dim3 grid(flat_blocks((long)n * h * w * 4));
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(pixels_to_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)rows, n, h, w, c, kw, dx0);
@@ -415,6 +417,7 @@ int pixels_to_rows_impl(const void* x, void* rows, int n, int h, int w, int c, i
 
 int rows_to_pixels_sum_impl(const void* rows, const void* addend, void* y, int n, int h, int w, int c, int kw, int dx0, int dtype,
                             hipStream_t s) {
+    STMI_REQUIRE((long)n * h * w * c < (1L << 31), "rows_to_pixels_sum: more than 2^31 work items");
     const dim3 grid(flat_blocks((long)n * h * w * c));
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(rows_to_pixels_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)rows, (const bf16_t*)addend, (bf16_t*)y, n, h, w, c, kw, dx0);
