@@ -41,6 +41,11 @@ class GradBuckets:
     def reduce_bucket(self, i):
         import torch.distributed as dist
         s, e = self.ranges[i]
+        if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo stages device tensors through the host from a thread of its own; issued behind a
+            # HIP-graph launch that is still in flight, that copy was observed never to complete.
+            # RCCL reductions are stream-ordered device work and need no such wait.
+            torch.cuda.current_stream().synchronize()
         self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
