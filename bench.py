@@ -50,11 +50,19 @@ def dist_setup(gpus):
     if gpus > 1 and world == 1:
         raise SystemExit('--gpus %d needs one process per GPU: launch with python -m torch.distributed.run '
                          '--nproc-per-node %d' % (gpus, gpus))
+    # Rehearsal on a box with fewer GPUs than ranks: STMI_BENCH_REHEARSE=1 puts every rank on GPU 0 and
+    # exchanges over gloo (RCCL wants one device per rank).  Numbers from such a run mean nothing.
+    rehearse = os.environ.get('STMI_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     return world, rank, torch.device('cuda', local)
 
 
