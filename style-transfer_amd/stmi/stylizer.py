@@ -235,12 +235,23 @@ class StylizerNet:
                     main.wait_event(ev)
             return free[0], free[1]
 
-        def on_side(buf, fn):
-            """The parameter-gradient kernels only feed the optimizer: they run beside the chain."""
+        def fork():
+            """Marks the point of the chain a side-stream job depends on."""
+            if side is None:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return ev
+
+        def on_side(buf, fn, after):
+            """The parameter-gradient kernels only feed the optimizer: they run beside the chain.
+            They are issued AFTER the chain's next kernel (and wait only for `after`, the fork
+            point): a captured graph keeps the first-issued successor of a node on the node's
+            own hardware queue, and a hop to another queue costs the chain several microseconds."""
             if side is None:
                 fn()
                 return
-            side.wait_stream(main)
+            side.wait_event(after)
             with torch.cuda.stream(side):
                 fn()
                 ev = torch.cuda.Event()
@@ -258,22 +269,22 @@ class StylizerNet:
                                   ws=self.ws, out=dconv)
             rows_g = None
             if b.kind == 'deconv':
-                on_side(w0, lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True))
+                wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
             elif b.rows == 'in':      # rows_buf still holds the forward's input patches
-                def wg_in():
+                def wgrad():
                     ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
-                on_side(w0, wg_in)
             elif b.rows == 'out':
                 rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
 
-                def wg_out():
+                def wgrad():
                     ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
-                on_side(w0, wg_out)
             else:
-                on_side(w0, lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True))
+                wgrad = lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
+            forked = fork()
             if i == 0:
+                on_side(w0, wgrad, forked)
                 break
             n_in = self.n * b.in_h * b.in_w * b.ci
             dx = w1[:n_in].view(self.n, b.in_h, b.in_w, b.ci)
@@ -284,6 +295,7 @@ class StylizerNet:
                 ops.conv2d_dgrad(rows_g, b.wp_bwd, (b.k, 1, b.ci, 32), 1, (b.in_h, b.in_w), addend=addend, out=dx)
             else:
                 ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx)
+            on_side(w0, wgrad, forked)
             if b.role == 'a':
                 pending_skip = None
             g = dx

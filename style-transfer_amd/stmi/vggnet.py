@@ -118,6 +118,7 @@ class VggReplica:
         # (dedicated) tap buffers they run on a side stream beside the following layers.
         self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
         self._style_job = None
+        self._deferred = []  # (event at the tap, Gram index, tapped tensor) not yet issued on the side stream
 
     def _buf(self, pool, shape, avoid):
         n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -163,6 +164,7 @@ class VggReplica:
                         ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, want_pre=True, out=y, out_pre=pre)
                     else:
                         ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, out=y)
+                    self._flush_side()
                     self._tap(name, pre)
                     self._tap(rname, y)
                     cur = y
@@ -171,14 +173,29 @@ class VggReplica:
                 # last layer of the truncated network: no ReLU follows
                 y = self.content if name == self.content_name else self._buf(self._scratch, shape, (cur,))
                 ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=False, out=y)
+                self._flush_side()
                 self._tap(name, y)
                 cur = y
             elif name.startswith('pool'):
                 y = self.act[name] if self.keep else self._buf(self._scratch, shape, (cur,))
                 ops.maxpool_fwd(cur, out=y)
+                self._flush_side()
                 cur = y
             i += 1
+        self._flush_side()
         return self.grams, self.content
+
+    def _flush_side(self):
+        """Launches the Gram jobs whose tap has been passed on the side stream.  A captured graph keeps
+        the first-issued successor of a node on the node's own hardware queue, so the chain's next
+        kernel goes first and the side job second."""
+        for ev, li, tensor in self._deferred:
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                ops.gram_fwd(tensor, out=self.grams[li])
+                if self._style_job is not None:
+                    self._style_job(li)
+        self._deferred.clear()
 
     def _tap(self, name, tensor):
         if tensor is None:
@@ -186,11 +203,10 @@ class VggReplica:
         if name in self.style_names and self._want_grams:
             li = self.style_names.index(name)
             if self._side is not None:
-                self._side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
-                    ops.gram_fwd(tensor, out=self.grams[li])
-                    if self._style_job is not None:
-                        self._style_job(li)
+                # issued after the chain's next kernel (see _flush_side); it waits only for this point
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._deferred.append((ev, li, tensor))
             else:
                 ops.gram_fwd(tensor, out=self.grams[li])
                 if self._style_job is not None:
