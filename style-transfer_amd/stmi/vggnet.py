@@ -111,6 +111,9 @@ class VggReplica:
         if keep:
             self.s_packed = [torch.empty(ops.gram_packed_elems(batch, self.shape[nm][3]), dtype=dt, device=dev)
                              for nm in self.style_names]
+            # d(style loss)/d(tap) per style layer, written beside the forward chain; the backward
+            # chain's data-gradient kernels take it as an addend
+            self.gram_grad = [torch.empty(self.shape[nm], dtype=dt, device=dev) for nm in self.style_names]
             self.d_content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
             self.d_image = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
             self.tv_grad = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
@@ -131,8 +134,8 @@ class VggReplica:
     def forward(self, x_f32, want_grams=True, style_job=None):
         """Fills self.grams (5 x fp32 [n,c,c]) and self.content from an fp32 image batch in [0,1].
 
-        style_job(li): optional follow-up of Gram li (its loss term), launched right behind
-        it on the same stream."""
+        style_job(li, tap): optional follow-up of Gram li (its loss term and gradient), launched
+        right behind it on the same stream."""
         self._want_grams = want_grams
         self._style_job = style_job
         net = self.net
@@ -194,7 +197,7 @@ class VggReplica:
             with torch.cuda.stream(self._side):
                 ops.gram_fwd(tensor, out=self.grams[li])
                 if self._style_job is not None:
-                    self._style_job(li)
+                    self._style_job(li, tensor)
         self._deferred.clear()
 
     def _tap(self, name, tensor):
@@ -210,7 +213,7 @@ class VggReplica:
             else:
                 ops.gram_fwd(tensor, out=self.grams[li])
                 if self._style_job is not None:
-                    self._style_job(li)
+                    self._style_job(li, tensor)
         if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
             self.content.copy_(tensor)
 
@@ -227,13 +230,16 @@ class VggReplica:
         l_style, l_content, l_tv = losses[1:2], losses[2:3], losses[3:4]
 
         # style: sum_l mean((G_l - T_l)^2) * w / len(content outputs)   (model_utilities.py:396)
-        def style_term(li):
+        def style_term(li, tap):
             nm = self.style_names[li]
             c = self.shape[nm][3]
             hw = self.shape[nm][1] * self.shape[nm][2]
             ls = style_weight / float(n * c * c)
             ops.gram_mse_fwd_bwd(self.grams[li], style_targets[li], l_style, ls, 4.0 * ls / hw, net.dtype,
                                  out=self.s_packed[li])
+            # d(style term)/d(tap) = tap x S: everything it needs exists already, so it leaves the
+            # backward chain and joins it later as the addend of a data-gradient kernel
+            ops.gram_bwd(tap, self.s_packed[li], self.gram_grad[li], accumulate=False)
 
         ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
         self.forward(x_f32, style_job=style_term)
@@ -250,12 +256,13 @@ class VggReplica:
         names = net.names
         g = self.d_content
         idx = len(names) - 1
+        joined = set()  # style layers whose Gram gradient is already part of g
         while idx >= 0:
             name = names[idx]
             if name.startswith('conv'):
-                if name in self.style_names:
-                    li = self.style_names.index(name)
-                    ops.gram_bwd(self.pre[name], self.s_packed[li], g, accumulate=True)
+                if name in self.style_names and name not in joined:
+                    # no masked data-gradient kernel produced g (the tap feeds a pool): add it here
+                    ops.gram_bwd(self.pre[name], self.s_packed[self.style_names.index(name)], g, accumulate=True)
                 L = net.convs[name]
                 in_name = names[idx - 1] if idx > 0 else None
                 h, w = (self.shape[in_name][1], self.shape[in_name][2]) if in_name else (self.h, self.w)
@@ -272,7 +279,13 @@ class VggReplica:
                     g = self.d_image
                 elif in_name.startswith('relu'):
                     dx = self._buf(self._gbuf, self.shape[in_name], (g,))
-                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=self.act[in_name], out=dx)
+                    below = names[idx - 2]  # the conv under that ReLU: its Gram gradient joins after the mask
+                    addend = None
+                    if below in self.style_names and below in self.pre:
+                        addend = self.gram_grad[self.style_names.index(below)]
+                        joined.add(below)
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=self.act[in_name], addend=addend,
+                                     out=dx)
                     g = dx
                     idx -= 1  # the ReLU is folded into the mask
                 else:  # pool output feeds this conv

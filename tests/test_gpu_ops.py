@@ -128,7 +128,11 @@ def test_conv_transpose(cuda, dtype, case):
 
 
 IN_CASES = [(2, 9, 7, 32, 'relu', False), (2, 16, 16, 128, 'none', True), (1, 12, 10, 3, 'sigmoid', False),
-            (1, 40, 30, 64, 'relu', False), (1, 64, 48, 128, 'relu', False)]
+            (1, 40, 30, 64, 'relu', False), (1, 64, 48, 128, 'relu', False),
+            (4, 64, 64, 128, 'none', True),      # the residual-block shape of the training step
+            (2, 128, 96, 32, 'sigmoid', False),
+            (3, 70, 50, 3, 'sigmoid', False),    # scalar fold (odd channel count), several blocks
+            (1, 600, 700, 32, 'none', True)]    # a large plane: the maximum number of partial rows per sample
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
@@ -161,6 +165,23 @@ def test_instance_norm_fwd_bwd(cuda, dtype, case):
     assert rel_err(dx, gx) <= TOL[dtype]
     assert rel_err(dscale, gs) <= 1e-3
     assert rel_err(dshift, gh) <= 1e-3
+
+
+def test_instance_norm_workspace_is_reusable(cuda):
+    """One workspace serves calls of different shapes in a row, and a repeated call gives the same bits."""
+    from stmi import ops
+    ws = ops.instance_norm_ws(4, 64, 64, 128, cuda)
+    outs = []
+    for shape in [(4, 64, 64, 128), (2, 33, 47, 64), (4, 64, 64, 128), (1, 50, 50, 3)]:
+        n, h, w, c = shape
+        x = (rnd(shape, 7) * 2 + 1).to(cuda, torch.bfloat16)
+        sc, sh = (rnd((c,), 8) + 1.5).to(cuda, torch.float32), rnd((c,), 9).to(cuda, torch.float32)
+        y, stats = ops.instance_norm_fwd(x, sc, sh, ops.ACT_RELU, ws=ws)
+        ds, dh = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+        dx = ops.instance_norm_bwd(x, y, stats, sc, sh, ds, dh, ops.ACT_RELU, ws=ws)
+        assert bool(torch.isfinite(dx.float()).all()) and bool(torch.isfinite(stats).all())
+        outs.append((y.clone(), dx.clone()))
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
