@@ -121,7 +121,7 @@ class VggReplica:
         # (dedicated) tap buffers they run on a side stream beside the following layers.
         self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
         self._style_job = None
-        self._deferred = []  # (event at the tap, Gram index, tapped tensor) not yet issued on the side stream
+        self._deferred = []  # (event at the fork point, job) not yet issued on the side stream
 
     def _buf(self, pool, shape, avoid):
         n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -189,16 +189,19 @@ class VggReplica:
         return self.grams, self.content
 
     def _flush_side(self):
-        """Launches the Gram jobs whose tap has been passed on the side stream.  A captured graph keeps
+        """Launches the side-stream jobs whose fork point has been passed.  A captured graph keeps
         the first-issued successor of a node on the node's own hardware queue, so the chain's next
         kernel goes first and the side job second."""
-        for ev, li, tensor in self._deferred:
+        for ev, job in self._deferred:
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                ops.gram_fwd(tensor, out=self.grams[li])
-                if self._style_job is not None:
-                    self._style_job(li, tensor)
+                job()
         self._deferred.clear()
+
+    def _gram_job(self, li, tensor):
+        ops.gram_fwd(tensor, out=self.grams[li])
+        if self._style_job is not None:
+            self._style_job(li, tensor)
 
     def _tap(self, name, tensor):
         if tensor is None:
@@ -209,11 +212,9 @@ class VggReplica:
                 # issued after the chain's next kernel (see _flush_side); it waits only for this point
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
-                self._deferred.append((ev, li, tensor))
+                self._deferred.append((ev, lambda: self._gram_job(li, tensor)))
             else:
-                ops.gram_fwd(tensor, out=self.grams[li])
-                if self._style_job is not None:
-                    self._style_job(li, tensor)
+                self._gram_job(li, tensor)
         if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
             self.content.copy_(tensor)
 
@@ -241,7 +242,14 @@ class VggReplica:
             # backward chain and joins it later as the addend of a data-gradient kernel
             ops.gram_bwd(tap, self.s_packed[li], self.gram_grad[li], accumulate=False)
 
-        ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+        # the TV term needs only the image and its gradient joins at the very end: beside the chain
+        tv = lambda: ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._deferred.append((ev, tv))
+        else:
+            tv()
         self.forward(x_f32, style_job=style_term)
         self._style_job = None
         if content_stream is not None:
