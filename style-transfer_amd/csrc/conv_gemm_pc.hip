@@ -258,19 +258,23 @@ static int launch_pc(const ConvGemmParams& p, hipStream_t s, char* name, int nam
 }
 
 // Tile choice: 128 x 64 when that still gives the chip most of a block per CU, else 64 x 64;
-// 32-row weight sets take 32 x 128.  (128 x 128 does not fit the 168-register budget of a
+// 32-row weight sets take 32 x 128; 64-byte rows take 128 or 256 pixels by the number of K steps.  (128 x 128 does not fit the 168-register budget of a
 // 768-thread block without spilling.)  STMI_PC_CFG=1|2 forces a configuration (tuning aid).
 template <typename T>
 static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char* name, int name_len, const char* tname) {
     if (rb == 64) {
-        if (p.co_pad % 64 == 0) return launch_pc<T, 2, 4, 64>(p, s, name, name_len, tname);
-        return launch_pc<T, 1, 4, 64>(p, s, name, name_len, tname);
+        // 256-pixel tiles once a block has enough K steps to amortise its start and its epilogue
+        // (the 9-tap layers); the 3-step conv1_1 row form is bound by its stores and keeps 128
+        const bool deep = p.ntaps * (p.klen / (64 / (int)sizeof(T))) >= 6;
+        if (p.co_pad % 64 == 0)
+            return deep ? launch_pc<T, 2, 8, 64>(p, s, name, name_len, tname) : launch_pc<T, 2, 4, 64>(p, s, name, name_len, tname);
+        return deep ? launch_pc<T, 1, 8, 64>(p, s, name, name_len, tname) : launch_pc<T, 1, 4, 64>(p, s, name, name_len, tname);
     }
     if (p.co_pad % 64 != 0) return launch_pc<T, 1, 4, 128>(p, s, name, name_len, tname);
     int cfg = 0;
     if (const char* f = getenv("STMI_PC_CFG")) cfg = atoi(f);
     if (cfg != 1 && cfg != 2) cfg = p.co_pad % 128 == 0 && pc_tiles(p, 128, 64) >= 192 ? 1 : 2;
-    if (cfg == 1 && p.co_pad % 128 != 0) cfg = 2;
+    if (cfg == 1 && (p.co_pad % 128 != 0 || sizeof(T) == 4)) cfg = 2;  // the fp32 128 x 64 tile spills registers
     if (cfg == 1) return launch_pc<T, 4, 2, 128>(p, s, name, name_len, tname);
     return launch_pc<T, 2, 2, 128>(p, s, name, name_len, tname);
 }
