@@ -204,6 +204,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--host-input', action='store_true',
+                    help='train: copy the batch from pinned host memory inside every timed step (PCIe-inclusive rate)')
     args = ap.parse_args()
 
     world, rank, device = dist_setup(args.gpus)
@@ -226,7 +228,15 @@ def main():
         tr.set_style_image(torch.from_numpy(style))
         tr.batch_in.copy_(torch.from_numpy(batch))
         torch.cuda.synchronize()
-        secs = timed_steps(lambda: tr.step(), args.steps, args.warmup, world, device)
+        if args.host_input:
+            pinned = torch.from_numpy(batch).pin_memory()
+
+            def step_from_host():
+                tr.batch_in.copy_(pinned, non_blocking=True)
+                tr.step()
+            secs = timed_steps(step_from_host, args.steps, args.warmup, world, device)
+        else:
+            secs = timed_steps(lambda: tr.step(), args.steps, args.warmup, world, device)
         losses = tr.read_losses()
         line.update({'metric': 'train img/s (VGG19 Gram loss)', 'unit': 'img/s',
                      'value': round(B * world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
@@ -234,7 +244,7 @@ def main():
                      'config': {'workload': 'stylizer training step, batch 4x256x256 per GPU, VGG19 perceptual + Gram '
                                 'style loss (starry_night_transfer weights), synthetic COCO-shaped batch',
                                 'global_batch': B * world, 'image': '256x256', 'parallelism': 'dp%d' % world,
-                                'hip_graph': not args.no_graph},
+                                'hip_graph': not args.no_graph, 'input': 'pinned host memory, copied every step' if args.host_input else 'resident in HBM'},
                      'final_losses': {'total': float(losses[0]), 'style': float(losses[1]),
                                       'content': float(losses[2]), 'tv': float(losses[3])}})
         if rank == 0 and world == 1:
