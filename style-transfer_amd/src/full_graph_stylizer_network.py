@@ -108,21 +108,42 @@ def save_checkpoint(params, model_dir, model_name, global_step=0):
 
 
 def latest_checkpoint(model_dir):
-    """Path of the newest weight file in model_dir, or None (tf.train.latest_checkpoint's role)."""
+    """Path of the newest weight file in model_dir, or None (tf.train.latest_checkpoint's role):
+    the `.npz` this build writes, or the `.index` of a checkpoint the reference's Saver wrote."""
     marker = os.path.join(model_dir, 'checkpoint')
     if os.path.exists(marker):
         with open(marker) as fl:
             for line in fl:
                 if line.startswith('model_checkpoint_path:'):
-                    base = line.split(':', 1)[1].strip().strip('"')
-                    path = os.path.join(model_dir, base + '.npz')
-                    if os.path.exists(path):
-                        return path
-    found = sorted(x for x in os.listdir(model_dir) if x.endswith('.npz')) if os.path.isdir(model_dir) else []
-    return os.path.join(model_dir, found[-1]) if found else None
+                    base = os.path.basename(line.split(':', 1)[1].strip().strip('"'))
+                    for ext in ('.npz', '.index'):
+                        path = os.path.join(model_dir, base + ext)
+                        if os.path.exists(path):
+                            return path
+    names = os.listdir(model_dir) if os.path.isdir(model_dir) else []
+    for ext in ('.npz', '.index'):
+        found = sorted(x for x in names if x.startswith('saved_') and x.endswith(ext))
+        if found:
+            return os.path.join(model_dir, found[-1])
+    return None
 
 
 def load_checkpoint(path):
+    """The 48 stylizer arrays in creation order, from this build's `.npz` or from a TensorFlow
+    tensor-bundle checkpoint (`saved_<name>-0.index` + `.data-00000-of-00001`, what
+    full_graph_stylizer_network.py:183/:231 of the reference saves and :366-367 restores; its
+    Adam slots and beta powers are ignored)."""
+    if path.endswith('.index'):
+        import tf_bundle
+        prefix = path[:-len('.index')]
+        have = tf_bundle.list_bundle(prefix)
+        count = 0
+        while _var_key(count) in have:
+            count += 1
+        if count == 0:
+            raise KeyError('%s holds no style_network/Variable* tensors' % path)
+        got = tf_bundle.read_bundle(prefix, [_var_key(i) for i in range(count)])
+        return [got[_var_key(i)] for i in range(count)]
     with np.load(path) as z:
         return [z[_var_key(i)] for i in range(len(z.files))]
 
@@ -302,7 +323,7 @@ class StyleNetService(threading.Thread):
             model_dir = self.model_name   # the 4-argument CLI form hands over an already joined path
         path = latest_checkpoint(model_dir)
         if path is None:
-            raise FileNotFoundError('no saved_*.npz weight file in ' + model_dir)
+            raise FileNotFoundError('no saved_*.npz or saved_*.index weight file in ' + model_dir)
         self._params = load_checkpoint(path)
         self._device = _device()
         print('StyleNetService running.')
