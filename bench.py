@@ -93,18 +93,17 @@ def timed_steps(step_fn, steps, warmup, world, device):
     return max_over_ranks(time.perf_counter() - t0, world, device)
 
 
-def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the committed counter passes
-    (profiles/r01_pmc_traffic.json, written by scripts/make_pmc.sh + scripts/pmc_summary.py: counters
-    cannot be collected from inside this process); None when the kernel is not listed there."""
+def pmc_entry(kernel_name):
+    """Counter figures of `kernel_name` from the committed counter passes (profiles/r01_pmc_traffic.json,
+    written by scripts/make_pmc.sh + scripts/pmc_summary.py: counters cannot be collected from inside this
+    process): HBM-side bytes per launch, MFMA FLOP per launch, MFMA busy fraction; {} when not listed."""
     import json
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
     try:
         with open(path) as f:
-            entry = json.load(f)['kernels'].get(kernel_name)
+            return json.load(f)['kernels'].get(kernel_name) or {}
     except (OSError, ValueError, KeyError):
-        return None
-    return None if entry is None else entry['bytes_per_launch']
+        return {}
 
 
 def roofline_train(trainer, dtype_name):
@@ -152,11 +151,13 @@ def roofline_train(trainer, dtype_name):
         acc[name] = (sum(f for f, _ in calls), e0.elapsed_time(e1) * 1e-3 / reps, len(calls))
     name, (flops, secs, launches) = max(acc.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
+    pmc = pmc_entry(name)
     peak = PEAK_TFLOPS[dtype_name]
     total = sum(v[1] for v in acc.values())
     return {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-        'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name), 'traffic_unit': 'bytes per launch',
+        'frac': round(achieved / peak, 4), 'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'bytes per launch',
+        'mfma_busy_frac_pmc': pmc.get('mfma_busy_frac'), 'mfma_flop_per_launch_pmc': pmc.get('mfma_flop_per_launch'),
         'kernel': name,
         'launches_per_step': launches, 'avg_launch_us': round(secs / launches * 1e6, 2),
         'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),

@@ -4,10 +4,21 @@ FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide (16 B per
 their size, so it is doubled (the kernels here read 16 B per lane throughout)."""
 import csv, glob, json, sys, collections, re
 
+def step_rows(path):
+    """Rows of the last two training steps only (a step ends with the multi-tensor weight repack): the run
+    also holds the one-off style-image pass, whose launches are many times larger than a step's."""
+    rows = list(csv.DictReader(open(path)))
+    marks = sorted({int(r['Dispatch_Id']) for r in rows if 'pack_weights_multi' in r['Kernel_Name']})
+    if len(marks) < 3:
+        return rows
+    lo, hi = marks[-3], marks[-1]
+    return [r for r in rows if lo < int(r['Dispatch_Id']) <= hi]
+
+
 def load(d):
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
+    for r in step_rows(f):
         agg[r['Kernel_Name']][0] += 1
         agg[r['Kernel_Name']][1] += float(r['Counter_Value'])
     return agg
@@ -23,7 +34,22 @@ def demangled(name):
     return 'void stmi::%s<%s, %s>(stmi::%s)' % (m.group(1), '__bf16' if m.group(2) == 'DF16b' else 'float', args,
                                                  'WgradParams' if 'wgrad' in m.group(1) else 'ConvGemmParams')
 
-fe, wr = load('gpurun_out/pmc_fetch'), load('gpurun_out/pmc_write')
+def load_mfma(d):
+    """Per kernel: launches, MFMA busy cycles, MFMA ops (x512 = FLOP), chip-active cycles (summed over the 8 XCDs)."""
+    files = glob.glob(d + '/*/*counter_collection.csv')
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    if not files:
+        return agg
+    seen = set()
+    for r in step_rows(files[0]):
+        k = r['Kernel_Name']
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            agg[k]['launches'] += 1
+    return agg
+
+fe, wr, mf = load('gpurun_out/pmc_fetch'), load('gpurun_out/pmc_write'), load_mfma('gpurun_out/pmc_mfma')
 out = {}
 for k, (n, v) in fe.items():
     if 'stmi' not in k:
@@ -32,7 +58,15 @@ for k, (n, v) in fe.items():
     out[demangled(k)] = {'launches': n, 'fetch_bytes_per_launch': round(2 * v / n * 1024),
                          'write_bytes_per_launch': round(w[1] / max(w[0], 1) * 1024),
                          'bytes_per_launch': round((2 * v / n + w[1] / max(w[0], 1)) * 1024)}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1; '
-                     'FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64)', 'kernels': out},
+    m = mf.get(k)
+    if m and m['launches'] and m['GRBM_GUI_ACTIVE']:
+        # 1024 SIMDs; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' active cycles
+        out[demangled(k)].update({
+            'mfma_flop_per_launch': round(m['SQ_INSTS_VALU_MFMA_MOPS_BF16'] * 512 / m['launches']),
+            'mfma_busy_frac': round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024), 4)})
+json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 '
+                     'GRBM_GUI_ACTIVE), separate passes, bench.py --steps 3 --warmup 1 with STMI_SERIAL=gwc, launches of the last two steps only (no concurrent '
+                     'kernels: the counters are chip-wide); FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64); '
+                     'mfma_busy_frac = MFMA busy cycles / (active cycles x 1024 SIMDs)', 'kernels': out},
           open(sys.argv[1], 'w'), indent=1, sort_keys=True)
 print(len(out), 'kernels ->', sys.argv[1])
