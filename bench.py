@@ -119,14 +119,17 @@ def roofline_train(trainer, dtype_name):
     trainer.use_graph = False
     trainer.step()
     torch.cuda.synchronize()
-    ops.PROFILE = []
+    ops.PROFILE, ops.PROFILE_HBM = [], []
     trainer.step()
     torch.cuda.synchronize()
     log, ops.PROFILE = ops.PROFILE, None
+    hbm_log, ops.PROFILE_HBM = ops.PROFILE_HBM, None
     trainer.use_graph = trainer_graph
     groups = {}
     for name, flops, relaunch in log:
         groups.setdefault(name, []).append((flops, relaunch))
+    for name, nbytes, relaunch in hbm_log:
+        groups.setdefault('hbm:' + name, []).append((nbytes, relaunch))
     reps, acc = 10, {}
     for name, calls in groups.items():
         side = torch.cuda.Stream()
@@ -149,6 +152,12 @@ def roofline_train(trainer, dtype_name):
         e1.record()
         torch.cuda.synchronize()
         acc[name] = (sum(f for f, _ in calls), e0.elapsed_time(e1) * 1e-3 / reps, len(calls))
+    # bandwidth-bound calls: algorithmic bytes / time against the HBM peak
+    hbm = {k[4:]: {'achieved': round(v[0] / v[1] / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                   'frac': round(v[0] / v[1] / 8e12, 4), 'calls_per_step': v[2],
+                   'algorithmic_mb_per_step': round(v[0] / 1e6, 1), 'us_per_step': round(v[1] * 1e6, 1)}
+           for k, v in acc.items() if k.startswith('hbm:')}
+    acc = {k: v for k, v in acc.items() if not k.startswith('hbm:')}
     name, (flops, secs, launches) = max(acc.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
     pmc = pmc_entry(name)
@@ -158,7 +167,7 @@ def roofline_train(trainer, dtype_name):
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'bytes per launch',
         'mfma_busy_frac_pmc': pmc.get('mfma_busy_frac'), 'mfma_flop_per_launch_pmc': pmc.get('mfma_flop_per_launch'),
-        'kernel': name,
+        'kernel': name, 'hbm_bound_calls': hbm,
         'launches_per_step': launches, 'avg_launch_us': round(secs / launches * 1e6, 2),
         'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
         'all_conv_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'launches_per_step': v[2],

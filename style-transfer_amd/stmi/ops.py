@@ -48,6 +48,8 @@ def same_out(size, stride):
 # forward / backward-data call appends (name of the kernel the library launched, algorithmic
 # flops, a closure that launches the same call again on the then-current stream).
 PROFILE = None
+# The same for the bandwidth-bound calls (instance norm): (call name, algorithmic bytes, relaunch closure).
+PROFILE_HBM = None
 
 
 def last_conv_kernel():
@@ -251,11 +253,16 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
         y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out_f32 is None else out_f32
     if residual is not None:
         _chk(residual, 'residual', x.dtype, x.shape)
-    s = _stream()
-    _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps),
-              n, h, w, c, _dt(x), s)
-    _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), stats.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-              _ptr(residual), y.data_ptr(), _ptr(y32), act, n, h, w, c, _dt(x), s)
+    def launch():
+        s = _stream()
+        _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps),
+                  n, h, w, c, _dt(x), s)
+        _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), stats.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  _ptr(residual), y.data_ptr(), _ptr(y32), act, n, h, w, c, _dt(x), s)
+    launch()
+    if PROFILE_HBM is not None:  # one read and one write of the activation (+ the skip tensor, + the fp32 copy)
+        nbytes = x.numel() * x.element_size() * (2 + (residual is not None)) + (0 if y32 is None else 4 * x.numel())
+        PROFILE_HBM.append(('instance_norm_fwd', nbytes, launch))
     return (y, stats, y32) if want_f32 else (y, stats)
 
 
@@ -270,9 +277,13 @@ def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, 
     if ws is None:
         ws = instance_norm_ws(n, h, w, c, x.device)
     dx = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
-    _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
-              shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), ws.data_ptr(), float(eps), act,
-              n, h, w, c, _dt(x), _stream())
+    def launch():
+        _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), ws.data_ptr(), float(eps), act,
+                  n, h, w, c, _dt(x), _stream())
+    launch()
+    if PROFILE_HBM is not None:  # read x and dy once, write dx once
+        PROFILE_HBM.append(('instance_norm_bwd', 3 * x.numel() * x.element_size(), launch))
     return dx
 
 
