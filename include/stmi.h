@@ -43,6 +43,10 @@ extern "C" {
 #define STMI_PACK_DGRAD 1 /* conv backward-data; transposed-conv forward */
 #define STMI_PACK_FWD_ROWOUT 2 /* conv forward producing (kx, co) row patches, kw*co <= 32: packed like
                                 * the STMI_PACK_FWD weights of a [kh,1,ci,32] conv (see row patches below) */
+#define STMI_PACK_FWD_RGB 3    /* forward weights of a 3-channel-input k x k stride-1 convolution for
+                                  stmi_conv2d_rgb_nhwc_fwd: co rows (co a multiple of 16) of
+                                  round_up(4*k*(k+1), 32) K elements, k = (ky*(k+1) + kx)*4 + c,
+                                  zero where kx >= k or c == 3 */
 
 /* ---- library ---------------------------------------------------------- */
 int stmi_version(void);
@@ -82,6 +86,16 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
 int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
                          int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                          int relu, int dtype, void* stream);
+
+/* The same convolution for a THREE-channel fp32 image, stride 1 (the stylizer's first layer,
+ * full_graph_stylizer_network.py:47; VGG conv1_1, vgg.py:92-96), with the input transformed while it
+ * is read: conv(x*scale - mean[c]) - scale = 1, mean = NULL is the plain cast; scale = 255/2 with the
+ * mean pixel is vgg_preprocess_input (vgg.py:11-17); the zero padding applies to the transformed
+ * image, as in the reference where the preprocessing is a separate op.  x_f32 [n,h,w,3] fp32 ->
+ * y [n,h,w,co] in dtype; W packed with STMI_PACK_FWD_RGB.  Built for (k, co) = (9, 32), (3, 64), (3, 32). */
+int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean, const void* w_packed_rgb,
+                             const float* bias, void* y, void* y_pre,
+                             int n, int h, int w, int co, int k, int relu, int dtype, void* stream);
 
 /* Gradient of the above w.r.t. x (what tf.gradients emits as Conv2DBackpropInput
  * for the ops at model_utilities.py:237 and :164):

@@ -20,15 +20,23 @@ from stmi.trainer import StyleTrainer
 ap = argparse.ArgumentParser()
 ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--full', action='store_true', help='print every call, not only the per-entry totals')
+ap.add_argument('--infer', action='store_true', help='16 x 1080p stylizer forward instead of the training step')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 rng = np.random.default_rng(1234)
-tr = StyleTrainer(4, 256, 256, dev, bench.synthetic_vgg(), np.zeros(3, np.float32), *bench.STARRY, dtype=dtype,
-                  params=init_params(seed=1), world_size=1, use_graph=False)
-tr.set_style_image(torch.from_numpy(np.random.default_rng(99).random((1, 1014, 1280, 3), dtype=np.float32)))
-tr.batch_in.copy_(torch.from_numpy(rng.random((4, 256, 256, 3), dtype=np.float32)))
-tr.step(); tr.step(); torch.cuda.synchronize()
+if args.infer:
+    from stmi.stylizer import StylizerNet
+    net = StylizerNet(16, 1080, 1920, dev, dtype, params=init_params(seed=1))
+    frames = torch.from_numpy(rng.random((16, 1080, 1920, 3), dtype=np.float32)).to(dev)
+    step = lambda: net.forward(frames)
+else:
+    tr = StyleTrainer(4, 256, 256, dev, bench.synthetic_vgg(), np.zeros(3, np.float32), *bench.STARRY, dtype=dtype,
+                      params=init_params(seed=1), world_size=1, use_graph=False)
+    tr.set_style_image(torch.from_numpy(np.random.default_rng(99).random((1, 1014, 1280, 3), dtype=np.float32)))
+    tr.batch_in.copy_(torch.from_numpy(rng.random((4, 256, 256, 3), dtype=np.float32)))
+    step = tr.step
+step(); step(); torch.cuda.synchronize()
 
 LOG = []
 orig_call = lib.call
@@ -40,12 +48,12 @@ def recording_call(name, *a):
         LOG.append((name, a, kern))
     return rc
 lib.call = recording_call
-tr.step()
+step()
 torch.cuda.synchronize()
 lib.call = orig_call
 LOG = [e for e in LOG if e[0] != 'stmi_last_conv_kernel']
 
-def timed(name, a, n=8):
+def timed(name, a, n=2 if args.infer else 8):
     cur = torch.cuda.current_stream()
     def go():
         orig_call(name, *a[:-1], torch.cuda.current_stream().cuda_stream)

@@ -246,6 +246,7 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
 }
 
 const char* last_conv_kernel() { return g_last_conv_kernel; }
+void set_last_conv_kernel(const char* name) { snprintf(g_last_conv_kernel, sizeof(g_last_conv_kernel), "%s", name); }
 
 // rows of a packed weight set are padded so that every block tile height divides them
 int packed_rows(int rows) {
@@ -254,6 +255,8 @@ int packed_rows(int rows) {
     if (rows > 16) return 32;
     return 16;
 }
+
+int conv_rgb_klen(int k);  // conv_rgb.hip
 
 static bool row_mode(int kchannels) { return (kchannels % 8) != 0; }
 
@@ -267,6 +270,14 @@ PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
         g.ntaps = kh;
         g.klen = ci;
         g.kpad = round_up(ci, 32);
+        return g;
+    }
+    if (mode == STMI_PACK_FWD_RGB) {  // conv_rgb.hip: co rows of ky-major runs of (kw + 1) four-channel pixels
+        g.rows = co;
+        g.rows_pad = round_up(co, 16);
+        g.row = false;
+        g.ntaps = 1;
+        g.klen = g.kpad = conv_rgb_klen(kh);
         return g;
     }
     const int kch = mode == STMI_PACK_FWD ? ci : co;
@@ -290,6 +301,10 @@ __device__ __forceinline__ void pack_range(const float* __restrict__ w, T* __res
         float v = 0.f;
         if (mode == STMI_PACK_FWD_ROWOUT) {
             if (row < g.rows && e < g.klen) v = w[(((long)t * kw + row / co) * ci + e) * co + row % co];
+        } else if (mode == STMI_PACK_FWD_RGB) {
+            const int run = 4 * (kw + 1);
+            const int ky = e / run, r = e - ky * run, kx = r >> 2, c = r & 3;
+            if (row < g.rows && ky < kh && kx < kw && c < ci) v = w[(((long)ky * kw + kx) * ci + c) * co + row];
         } else if (row < g.rows && e < g.klen) {
             int ky, kx, kc;
             const int kch = mode == STMI_PACK_FWD ? ci : co;

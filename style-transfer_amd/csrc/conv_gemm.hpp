@@ -241,6 +241,9 @@ __device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, co
     conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wave / WP, wave % WP, lane >> 4, lane & 15, Mz, zoff, HWs);
 }
 
+// Name (as a profiler prints it) of the conv kernel launched last by this thread.
+void set_last_conv_kernel(const char* name);
+
 // LDS-DMA variant (conv_gemm_glds.hip).  Returns true and launches when the problem fits
 // it (K per tap a multiple of 128 bytes, per-pixel validity); *rc receives the status.
 bool try_launch_conv_gemm_glds(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc);

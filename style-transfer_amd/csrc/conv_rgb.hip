@@ -1,0 +1,185 @@
+// Stride-1 SAME convolution of a 3-channel fp32 image (gfx950): the stylizer's first 9x9 layer
+// (full_graph_stylizer_network.py:47 -> model_utilities.py:235-242) and VGG conv1_1 (vgg.py:92-96,
+// with the preprocessing of vgg.py:11-17 applied while the image is read).
+//
+// With 3 input channels a tap has 6 bytes of K: no gather-GEMM tile shape fits it.  Here a block
+// owns an 8 x 32 rectangle of output pixels and keeps its input patch in LDS with the pixels
+// padded to FOUR channels (one pixel = 4 elements = 8 bytes of bf16 / 16 bytes of fp32).  A
+// kernel row then is a run of RUNPX = K + 1 pixels = 4 * RUNPX contiguous K elements at a pixel-
+// aligned LDS address, so the MFMA's 16-byte K fragments are plain LDS reads at 8-byte alignment
+// and the whole K axis is  ky-major runs: k = (ky * RUNPX + kx) * 4 + c, zero weights where
+// kx >= K or c == 3.  The weights (CO rows of KL = round_up(4 * K * RUNPX, 32) elements, packed with
+// STMI_PACK_FWD_RGB) sit in LDS beside the patch for the whole block.
+//
+// The image is read as fp32 and converted on the way in (x * scale - mean[c]), which folds the
+// cast of the stylizer's input and VGG's preprocessing into the convolution; the input never
+// exists as a 32-wide row-patch tensor.  Per output pixel the kernel reads 12 bytes and writes
+// 2 * CO (bf16): it is bound by its stores.
+#include "conv_gemm.hpp"
+
+namespace stmi {
+
+namespace {
+constexpr int kRgbPH = 8, kRgbPW = 32;  // output pixels per block: 4 waves x (2 rows x 32)
+}
+
+template <typename T, int K, int TC>
+__global__ __launch_bounds__(256) void conv_rgb_kernel(const float* __restrict__ x, float scale, const float* mean,
+                                                       const T* __restrict__ wq, const ConvGemmParams p) {
+    constexpr int EPC = 16 / (int)sizeof(T);     // elements per 16-byte K fragment
+    constexpr int RUNPX = K + 1;                 // pixels per kernel-row run (K is odd)
+    constexpr int CPK = RUNPX * 4 / EPC;         // fragments per run
+    constexpr int KL = (4 * K * RUNPX + 31) / 32 * 32;
+    constexpr int NCH = KL / EPC, NSTEP = NCH / 4;
+    constexpr int CO = 16 * TC, TP = 4;
+    constexpr int PH = kRgbPH, PW = kRgbPW, PAD = (K - 1) / 2;
+    constexpr int PHH = PH + K - 1, PWH = PW + RUNPX - 1;
+    constexpr int PIX_B = 4 * (int)sizeof(T);    // bytes per padded pixel
+    constexpr int W_STRIDE = KL * (int)sizeof(T) + 16;  // +16 bytes: sixteen rows hit sixteen bank groups
+    constexpr int W_BYTES = CO * W_STRIDE;
+    static_assert(RUNPX * 4 % EPC == 0 && NCH % 4 == 0, "runs and steps must be whole fragments");
+    typedef typename Mma<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* wl = lds;
+    char* pl = lds + W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.Hi, W = p.Wi;
+    const int tiles_x = (W + PW - 1) / PW, tiles_y = (H + PH - 1) / PH;
+    int t = blockIdx.x;
+    const int n = t / (tiles_x * tiles_y);
+    t -= n * tiles_x * tiles_y;
+    const int ty0 = (t / tiles_x) * PH, tx0 = (t % tiles_x) * PW;
+
+    // weights -> LDS, 16 bytes per access
+    for (int i = tid; i < CO * NCH; i += 256) {
+        const int row = i / NCH, q = i - row * NCH;
+        *reinterpret_cast<uint4*>(wl + row * W_STRIDE + q * 16) = *reinterpret_cast<const uint4*>(wq + (long)row * KL + q * EPC);
+    }
+    // patch -> LDS: fp32 image elements, preprocessed, converted; zeros outside the image and in channel 3
+    {
+        const float* img = x + (long)n * H * W * 3;
+        float m3[3] = {0.f, 0.f, 0.f};
+        if (mean) { m3[0] = mean[0]; m3[1] = mean[1]; m3[2] = mean[2]; }
+        for (int i = tid; i < PHH * PWH; i += 256) {
+            const int r = i / PWH, c = i - r * PWH;
+            const int iy = ty0 - PAD + r, ix = tx0 - PAD + c;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const float* s = img + ((long)iy * W + ix) * 3;
+                v[0] = s[0] * scale - m3[0];
+                v[1] = s[1] * scale - m3[1];
+                v[2] = s[2] * scale - m3[2];
+            }
+            T* d = reinterpret_cast<T*>(pl + (r * PWH + c) * PIX_B);
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = from_f32<T>(v[u]);
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; a++)
+#pragma unroll
+        for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    // patch position under tap (0, 0) of this lane's pixel in each of the wave's four fragments
+    int pbase[TP];
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++) {
+        const int f = wave * TP + tp;  // fragment f: row f / 2, columns (f % 2) * 16 ..
+        pbase[tp] = ((f >> 1) * PWH + (f & 1) * 16 + r16) * PIX_B;
+    }
+#pragma unroll
+    for (int s = 0; s < NSTEP; s++) {
+        const int q = 4 * s + g;
+        int ky = q / CPK;
+        const int cx = q - ky * CPK;
+        ky = ky < K ? ky : K - 1;  // past the last run the weights are zero: read something valid
+        const int koff = (ky * PWH) * PIX_B + cx * 16;
+        frag a[TC], b[TP];
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++) a[tc] = *reinterpret_cast<const frag*>(wl + (tc * 16 + r16) * W_STRIDE + q * 16);
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            const char* src = pl + pbase[tp] + koff;  // 8-byte aligned for bf16, 16 for fp32
+            uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+            uint4 v = {lo.x, lo.y, hi.x, hi.y};
+            b[tp] = __builtin_bit_cast(frag, v);
+        }
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) Mma<T>::mma(a[tc], b[tp], acc[tc][tp]);
+    }
+
+    constexpr int TPG = conv_stage_tpg(TC, TP, 1, 4, 160 * 1024 / 2);
+    static_assert(TPG >= 1, "staging area");
+    const long img_row = (long)n * H;
+    conv_epilogue_lds<T, TC, TP, 1, 4, 256, TPG>(p, acc, 0, reinterpret_cast<float*>(lds), [&](int pix) -> long {
+        const int f = pix >> 4;
+        const int oy = ty0 + (f >> 1), ox = tx0 + (f & 1) * 16 + (pix & 15);
+        return oy < H && ox < W ? ((img_row + oy) * W + ox) * p.Co : -1;
+    });
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int conv_rgb_klen(int k) { return (4 * k * (k + 1) + 31) / 32 * 32; }
+
+template <typename T, int K, int TC>
+static int launch_rgb(const float* x, float scale, const float* mean, const void* wq, const ConvGemmParams& p,
+                      hipStream_t s) {
+    constexpr int KL = (4 * K * (K + 1) + 31) / 32 * 32;
+    constexpr int CO = 16 * TC;
+    constexpr int W_BYTES = CO * (KL * (int)sizeof(T) + 16);
+    constexpr int P_BYTES = (kRgbPH + K - 1) * (kRgbPW + K) * 4 * (int)sizeof(T);
+    constexpr int TPG = conv_stage_tpg(TC, 4, 1, 4, 160 * 1024 / 2);
+    constexpr int S_BYTES = 16 * TPG * 4 * (CO + 4) * 4;
+    constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_BYTES ? W_BYTES + P_BYTES : S_BYTES) + 15) / 16 * 16;
+    static bool attr_set = false;  // idempotent; a racing second call is harmless
+    if (!attr_set) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
+                           "hipFuncSetAttribute(conv_rgb_kernel)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    {
+        char name[160];
+        snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d>(float const*, float, float const*, %s const*, stmi::ConvGemmParams)",
+                 sizeof(T) == 2 ? "__bf16" : "float", K, TC, sizeof(T) == 2 ? "__bf16" : "float");
+        set_last_conv_kernel(name);
+    }
+    const long tiles = (long)p.N * ceil_div(p.Hi, kRgbPH) * ceil_div(p.Wi, kRgbPW);
+    if (tiles <= 0) return STMI_OK;
+    STMI_REQUIRE(tiles < (1L << 31), "conv_rgb: too many tiles for one launch");
+    hipLaunchKernelGGL((conv_rgb_kernel<T, K, TC>), dim3((unsigned)tiles), dim3(256), kLds, s, x, scale, mean, (const T*)wq, p);
+    STMI_LAUNCH_CHECK("conv_rgb_kernel");
+    return STMI_OK;
+}
+
+int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
+                      void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s) {
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.out = y; p.out_pre = y_pre; p.bias = bias; p.alpha = 1.f; p.relu = relu;
+    p.N = n; p.Hi = h; p.Wi = w; p.Ci = 3;
+    p.Ho = h; p.Wo = w; p.Co = co;
+    const uintptr_t ptrs = (uintptr_t)y | (uintptr_t)y_pre | (uintptr_t)wq;
+    STMI_REQUIRE((ptrs & 15) == 0, "conv_rgb: y, y_pre and the packed weights must be 16-byte aligned");
+    STMI_REQUIRE((long)n * h * w * 3 < (1L << 31), "conv_rgb: image batch too large for 32-bit indexing");
+    p.row_store_ok = 1;
+    const bool bf = dtype == STMI_BF16;
+    if (k == 9 && co == 32) return bf ? launch_rgb<bf16_t, 9, 2>(x, scale, mean, wq, p, s) : launch_rgb<float, 9, 2>(x, scale, mean, wq, p, s);
+    if (k == 3 && co == 64) return bf ? launch_rgb<bf16_t, 3, 4>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 4>(x, scale, mean, wq, p, s);
+    if (k == 3 && co == 32) return bf ? launch_rgb<bf16_t, 3, 2>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 2>(x, scale, mean, wq, p, s);
+    set_error("conv_rgb: unsupported (k, co) = (%d, %d); built for (9, 32), (3, 64) and (3, 32)", k, co);
+    return STMI_ERR_INVALID;
+}
+
+}  // namespace stmi

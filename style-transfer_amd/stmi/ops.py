@@ -8,7 +8,7 @@ Tensors are NHWC, contiguous, on the current HIP device, float32 or bfloat16.
 import torch
 
 from . import lib as _lib
-from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD, PACK_FWD_ROWOUT  # noqa: F401
+from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD, PACK_FWD_RGB, PACK_FWD_ROWOUT  # noqa: F401
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -120,6 +120,33 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
     _conv_call('stmi_conv2d_nhwc_fwd', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
                                         n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x)),
                co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
+    return (y, pre) if want_pre else y
+
+
+RGB_CONFIGS = ((9, 32), (3, 64), (3, 32))  # (k, co) the 3-channel kernel is built for
+
+
+def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=None, relu=False, want_pre=False,
+                   out=None, out_pre=None):
+    """k x k stride-1 SAME convolution of an fp32 [n,h,w,3] image, computed in `dtype` on
+    x * scale - mean[c] (the cast / VGG preprocessing happens while the image is read).
+    w_packed: the [k,k,3,co] weight packed with PACK_FWD_RGB."""
+    n, h, w, c = x_f32.shape
+    assert c == 3 and (k, co) in RGB_CONFIGS, (c, k, co)
+    _chk(x_f32, 'x_f32', torch.float32)
+    _chk(w_packed, 'w_packed', dtype, (packed_elems(k, k, 3, co, PACK_FWD_RGB),))
+    oshape = (n, h, w, co)
+    y = torch.empty(oshape, dtype=dtype, device=x_f32.device) if out is None else _chk(out, 'out', dtype, oshape)
+    pre = None
+    if want_pre:
+        pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', dtype, oshape)
+    if bias is not None:
+        _chk(bias, 'bias', torch.float32, (co,))
+    if mean is not None:
+        _chk(mean, 'mean', torch.float32, (3,))
+    _conv_call('stmi_conv2d_rgb_nhwc_fwd', (x_f32.data_ptr(), float(scale), _ptr(mean), w_packed.data_ptr(), _ptr(bias),
+                                            y.data_ptr(), _ptr(pre), n, h, w, co, k, int(relu), _dt(y)),
+               co, n * h * w, 3, k * k, 1)
     return (y, pre) if want_pre else y
 
 

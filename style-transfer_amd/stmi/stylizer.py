@@ -101,9 +101,15 @@ class StylizerNet:
                 elif co % 8 != 0 and k * co <= 32 and c % 8 == 0:
                     b.rows = 'out'
                     fwd_mode = ops.PACK_FWD_ROWOUT
+            # the 3-channel first layer has a kernel of its own that reads the fp32 image directly; its
+            # input row patches are then needed by the weight gradient only
+            b.rgb = b.rows == 'in' and (k, co) in ops.RGB_CONFIGS and 'r' not in _SERIAL
+            if b.rgb:
+                fwd_mode = ops.PACK_FWD_RGB
             if b.rows:
                 b.pad_left = (k - 1) // 2
-                b.rows_buf = torch.empty((batch, h, w, 32), dtype=dtype, device=device)
+                b.rows_buf = (torch.empty((batch, h, w, 32), dtype=dtype, device=device)
+                              if training or not b.rgb else None)
                 if training:
                     b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
                                          device=device)
@@ -173,7 +179,9 @@ class StylizerNet:
 
     def forward(self, x_f32):
         """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32)."""
-        ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
+        self._x_f32 = x_f32
+        if not self.blocks[0].rgb:
+            ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
         cur = self.x_in
         skip = None
         last = len(self.blocks) - 1
@@ -187,6 +195,8 @@ class StylizerNet:
                 conv_out, y = self._view(free[0], b), self._view(free[1], b)
             if b.kind == 'deconv':
                 ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+            elif b.rgb:
+                ops.conv2d_rgb_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out)
             elif b.rows == 'in':
                 ops.pixels_to_rows(cur, b.k, -b.pad_left, out=b.rows_buf)
                 ops.conv2d_fwd(b.rows_buf, b.wp_fwd, (b.k, 1, 32, b.co), 1, out=conv_out)
@@ -270,8 +280,12 @@ class StylizerNet:
             rows_g = None
             if b.kind == 'deconv':
                 wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
-            elif b.rows == 'in':      # rows_buf still holds the forward's input patches
-                def wgrad():
+            elif b.rows == 'in':      # rows_buf still holds the forward's input patches, unless the forward
+                def wgrad():          # ran the 3-channel kernel: then they are made here, beside the chain
+                    if b.rgb:
+                        x32 = self._x_f32
+                        ops.cast(x32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x32)
+                        ops.pixels_to_rows(self.x_in, b.k, -b.pad_left, out=b.rows_buf)
                     ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
             elif b.rows == 'out':

@@ -15,7 +15,7 @@ import os
 from . import ops
 
 # tuning aid: STMI_SERIAL containing g / w / c keeps the Gram terms / weight gradients / content
-# targets on the main stream instead of a side stream
+# targets on the main stream instead of a side stream; r keeps the 3-channel layers on row patches
 _SERIAL = os.environ.get('STMI_SERIAL', '')
 
 LAYER_NAMES = [
@@ -61,6 +61,12 @@ class VggFeatures:
             # forward convolution 64 -> 3 with the flipped, transposed kernel, rows on the output
             # side; d(preprocess)/dx = 255/2 is folded into those weights.
             L.rows = L.kshape[2] < 8 and L.kshape[0] * L.kshape[2] <= 32 and L.kshape[3] % 8 == 0
+            # ... unless the 3-channel kernel is built for this layer: it reads the fp32 image and
+            # preprocesses it on the way in (forward only; the backward-data stays on row patches)
+            L.rgb = (L.kshape[2] == 3 and L.kshape[0] == L.kshape[1]
+                     and (L.kshape[0], L.kshape[3]) in ops.RGB_CONFIGS and 'r' not in _SERIAL)
+            if L.rgb:
+                L.wp_rgb = ops.pack_conv_weights(w, ops.PACK_FWD_RGB, dtype)
             if L.rows and with_backward:
                 wt = (w.flip(0, 1).permute(0, 1, 3, 2) * (255.0 / 2.0)).contiguous()
                 L.wp_bwd_rows = ops.pack_conv_weights(wt, ops.PACK_FWD_ROWOUT, dtype)
@@ -79,8 +85,10 @@ class VggReplica:
         self.style_names = STYLE_RELU_TAPS if relu_taps else STYLE_CONV_TAPS
         self.content_name = CONTENT_RELU_TAP if relu_taps else CONTENT_CONV_TAP
         assert not (keep and relu_taps), 'the backward pass is built for the pre-ReLU taps of the training path'
-        self.x_pre = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
-        self.rows_buf = torch.empty((batch, height, width, 32), dtype=dt, device=dev)   # row patches of x_pre
+        first = net.convs[net.names[0]]
+        if not first.rgb:
+            self.x_pre = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+            self.rows_buf = torch.empty((batch, height, width, 32), dtype=dt, device=dev)   # row patches of x_pre
         self.rows_gbuf = torch.empty((batch, height, width, 32), dtype=dt, device=dev) if keep else None
         self.act = {}      # name -> output buffer of that layer (post-ReLU for relu layers)
         self.pre = {}      # conv name -> pre-ReLU output where it is tapped
@@ -139,9 +147,13 @@ class VggReplica:
         self._want_grams = want_grams
         self._style_job = style_job
         net = self.net
-        ops.scale_shift(x_f32, net.mean, 255.0 / 2.0, net.dtype, out=self.x_pre)
-        cur = self.x_pre
         names = net.names
+        rgb_first = net.convs[names[0]].rgb
+        if rgb_first:
+            cur = x_f32
+        else:
+            ops.scale_shift(x_f32, net.mean, 255.0 / 2.0, net.dtype, out=self.x_pre)
+            cur = self.x_pre
         i = 0
         while i < len(names):
             name = names[i]
@@ -149,10 +161,19 @@ class VggReplica:
             if name.startswith('conv'):
                 L = net.convs[name]
                 kshape = L.kshape
-                if i == 0 and L.rows:
-                    k = kshape[0]
-                    cur = ops.pixels_to_rows(cur, k, -((k - 1) // 2), out=self.rows_buf)
-                    kshape = (k, 1, 32, kshape[3])
+                if i == 0 and rgb_first:
+                    def conv(src, relu, out, out_pre=None):
+                        ops.conv2d_rgb_fwd(src, L.wp_rgb, kshape[0], kshape[3], net.dtype, scale=255.0 / 2.0, mean=net.mean,
+                                           bias=L.bias, relu=relu, want_pre=out_pre is not None, out=out, out_pre=out_pre)
+                else:
+                    if i == 0 and L.rows:
+                        k = kshape[0]
+                        cur = ops.pixels_to_rows(cur, k, -((k - 1) // 2), out=self.rows_buf)
+                        kshape = (k, 1, 32, kshape[3])
+
+                    def conv(src, relu, out, out_pre=None, kshape=kshape):
+                        ops.conv2d_fwd(src, L.wp_fwd, kshape, 1, bias=L.bias, relu=relu, want_pre=out_pre is not None,
+                                       out=out, out_pre=out_pre)
                 has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
                 tap_pre = (not self.relu_taps) and want_grams and name in STYLE_CONV_TAPS
                 if has_relu:
@@ -163,10 +184,7 @@ class VggReplica:
                     else:
                         y = self._buf(self._scratch, shape, (cur,))
                         pre = self._buf(self._scratch, shape, (cur, y)) if tap_pre else None
-                    if pre is not None:
-                        ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, want_pre=True, out=y, out_pre=pre)
-                    else:
-                        ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=True, out=y)
+                    conv(cur, True, y, pre)
                     self._flush_side()
                     self._tap(name, pre)
                     self._tap(rname, y)
@@ -175,7 +193,7 @@ class VggReplica:
                     continue
                 # last layer of the truncated network: no ReLU follows
                 y = self.content if name == self.content_name else self._buf(self._scratch, shape, (cur,))
-                ops.conv2d_fwd(cur, L.wp_fwd, kshape, 1, bias=L.bias, relu=False, out=y)
+                conv(cur, False, y)
                 self._flush_side()
                 self._tap(name, y)
                 cur = y

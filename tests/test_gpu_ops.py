@@ -100,6 +100,42 @@ def test_conv_dgrad_epilogue(cuda, dtype, chans):
     assert rel_err(got, ref) <= TOL[dtype]
 
 
+RGB_CASES = [(2, 32, 64, 9, 32, False), (1, 37, 45, 9, 32, False), (2, 16, 32, 3, 64, True), (1, 21, 50, 3, 64, True),
+             (1, 9, 11, 3, 32, True), (4, 256, 256, 9, 32, False)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', RGB_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_rgb_matches_preprocess_then_conv(cuda, dtype, case):
+    """The 3-channel kernel = (x * scale - mean, rounded to the compute dtype) -> SAME conv
+    [+ bias, + pre-ReLU copy, + ReLU], including tiles clipped at both borders."""
+    from stmi import ops
+    n, h, w, k, co, vgg_like = case
+    x = rnd((n, h, w, 3), 1).abs().clamp(max=1.0)
+    wt = rnd((k, k, 3, co), 2, 1.0 / np.sqrt(k * k * 3))
+    scale, mean = (127.5, torch.tensor([123.68, 116.78, 103.94])) if vgg_like else (1.0, None)
+    bias = rnd((co,), 3) if vgg_like else None
+    xin = x.double() * scale - (mean.double() if mean is not None else 0.0)
+    if vgg_like:
+        xin, wt = xin / 64.0, wt    # keep magnitudes comparable; applied to the kernel through `scale` / `mean`
+        scale, mean = scale / 64.0, mean / 64.0
+    ref = O.conv2d_same(q(xin, dtype), q(wt, dtype), 1)
+    if bias is not None:
+        ref = ref + bias.double()
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD_RGB, dtype)
+    got = ops.conv2d_rgb_fwd(x.to(cuda, torch.float32), wp, k, co, dtype, scale=scale,
+                             mean=None if mean is None else mean.to(cuda, torch.float32),
+                             bias=None if bias is None else bias.to(cuda, torch.float32),
+                             relu=vgg_like, want_pre=vgg_like)
+    if vgg_like:
+        y, pre = got
+        assert rel_err(pre, ref) <= TOL[dtype]
+        assert rel_err(y, torch.relu(ref)) <= TOL[dtype]
+    else:
+        assert rel_err(got, ref) <= TOL[dtype]
+    assert 'conv_rgb_kernel' in ops.last_conv_kernel()
+
+
 DECONV_CASES = [(2, 6, 5, 128, 64, 3, 2), (1, 7, 8, 64, 32, 3, 2), (1, 4, 4, 16, 8, 3, 2)]
 
 
