@@ -47,6 +47,9 @@ extern "C" {
                                   stmi_conv2d_rgb_nhwc_fwd: co rows (co a multiple of 16) of
                                   round_up(4*k*(k+1), 32) K elements, k = (ky*(k+1) + kx)*4 + c,
                                   zero where kx >= k or c == 3 */
+#define STMI_PACK_DGRAD_RGB 4  /* backward-data weights of a k x k stride-1 convolution ci -> 3 for
+                                  stmi_conv2d_rgb_nhwc_dgrad: ci rows of the same K layout, built from the
+                                  flipped kernel with its channel axes exchanged */
 
 /* ---- library ---------------------------------------------------------- */
 int stmi_version(void);
@@ -96,6 +99,12 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
 int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean, const void* w_packed_rgb,
                              const float* bias, void* y, void* y_pre,
                              int n, int h, int w, int co, int k, int relu, int dtype, void* stream);
+
+/* Gradient w.r.t. the input of a k x k stride-1 convolution that WRITES three channels (the stylizer's
+ * last layer, full_graph_stylizer_network.py:78): dy [n,h,w,3] in dtype -> dx [n,h,w,ci]; W packed with
+ * STMI_PACK_DGRAD_RGB.  Built for (k, ci) = (9, 32). */
+int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, void* dx,
+                               int n, int h, int w, int ci, int k, int dtype, void* stream);
 
 /* Gradient of the above w.r.t. x (what tf.gradients emits as Conv2DBackpropInput
  * for the ops at model_utilities.py:237 and :164):

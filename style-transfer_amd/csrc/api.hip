@@ -30,6 +30,8 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
                       void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s);
+int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
+                        hipStream_t s);
 int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
                     int stride, int accumulate, int dtype, hipStream_t s);
 int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s);
@@ -108,9 +110,11 @@ long stmi_conv_packed_elems(int kh, int kw, int ci, int co, int mode) {
 int stmi_pack_conv_weights(const float* w_hwio, void* packed, int kh, int kw, int ci, int co, int mode, int dtype,
                            void* stream) {
     if (check_conv("pack_conv_weights", 0, 1, 1, ci, co, kh, kw, 1, dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(mode >= STMI_PACK_FWD && mode <= STMI_PACK_FWD_RGB, "pack_conv_weights: bad mode %d", mode);
+    STMI_REQUIRE(mode >= STMI_PACK_FWD && mode <= STMI_PACK_DGRAD_RGB, "pack_conv_weights: bad mode %d", mode);
     STMI_REQUIRE(mode != STMI_PACK_FWD_RGB || (ci == 3 && kh == kw && (kh & 1) && co % 16 == 0),
                  "pack_conv_weights: the 3-channel layout needs ci == 3, an odd square kernel and co %% 16 == 0");
+    STMI_REQUIRE(mode != STMI_PACK_DGRAD_RGB || (co == 3 && kh == kw && (kh & 1) && ci % 16 == 0),
+                 "pack_conv_weights: the 3-channel backward layout needs co == 3, an odd square kernel and ci %% 16 == 0");
     STMI_REQUIRE(mode != STMI_PACK_FWD_ROWOUT || (kw * co <= 32 && ci % 8 == 0),
                  "pack_conv_weights: row-patch output needs kw*co <= 32 and ci %% 8 == 0 (kw=%d co=%d ci=%d)", kw, co, ci);
     STMI_REQUIRE(w_hwio && packed, "pack_conv_weights: null pointer");
@@ -124,10 +128,12 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
     for (int i = 0; i < n; i++) {
         const stmi_pack_desc& d = descs[i];
         if (check_conv("pack_conv_weights_multi", 0, 1, 1, d.ci, d.co, d.kh, d.kw, 1, dtype)) return STMI_ERR_INVALID;
-        STMI_REQUIRE(d.mode >= STMI_PACK_FWD && d.mode <= STMI_PACK_FWD_RGB && d.src_off >= 0 && d.dst_off >= 0,
+        STMI_REQUIRE(d.mode >= STMI_PACK_FWD && d.mode <= STMI_PACK_DGRAD_RGB && d.src_off >= 0 && d.dst_off >= 0,
                      "pack_conv_weights_multi: bad descriptor %d", i);
         STMI_REQUIRE(d.mode != STMI_PACK_FWD_RGB || (d.ci == 3 && d.kh == d.kw && (d.kh & 1) && d.co % 16 == 0),
                      "pack_conv_weights_multi: descriptor %d: the 3-channel layout needs ci == 3, an odd square kernel and co %% 16 == 0", i);
+        STMI_REQUIRE(d.mode != STMI_PACK_DGRAD_RGB || (d.co == 3 && d.kh == d.kw && (d.kh & 1) && d.ci % 16 == 0),
+                     "pack_conv_weights_multi: descriptor %d: the 3-channel backward layout needs co == 3, an odd square kernel and ci %% 16 == 0", i);
         STMI_REQUIRE(d.mode != STMI_PACK_FWD_ROWOUT || (d.kw * d.co <= 32 && d.ci % 8 == 0),
                      "pack_conv_weights_multi: descriptor %d: row-patch output needs kw*co <= 32 and ci %% 8 == 0", i);
     }
@@ -149,6 +155,14 @@ int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean,
     STMI_REQUIRE(x_f32 && w_packed_rgb && y, "conv2d_rgb_nhwc_fwd: null pointer");
     if (n == 0) return STMI_OK;
     return conv_rgb_fwd_impl(x_f32, scale, mean, w_packed_rgb, bias, y, y_pre, n, h, w, co, k, relu, dtype, S(stream));
+}
+
+int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, void* dx, int n, int h, int w, int ci,
+                               int k, int dtype, void* stream) {
+    if (check_conv("conv2d_rgb_nhwc_dgrad", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(dy && w_packed_dgrad_rgb && dx, "conv2d_rgb_nhwc_dgrad: null pointer");
+    if (n == 0) return STMI_OK;
+    return conv_rgb_dgrad_impl(dy, w_packed_dgrad_rgb, dx, n, h, w, ci, k, dtype, S(stream));
 }
 
 int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,

@@ -272,9 +272,9 @@ PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
         g.kpad = round_up(ci, 32);
         return g;
     }
-    if (mode == STMI_PACK_FWD_RGB) {  // conv_rgb.hip: co rows of ky-major runs of (kw + 1) four-channel pixels
-        g.rows = co;
-        g.rows_pad = round_up(co, 16);
+    if (mode == STMI_PACK_FWD_RGB || mode == STMI_PACK_DGRAD_RGB) {  // conv_rgb.hip: rows of ky-major runs of (kw + 1) four-channel pixels
+        g.rows = mode == STMI_PACK_FWD_RGB ? co : ci;
+        g.rows_pad = round_up(g.rows, 16);
         g.row = false;
         g.ntaps = 1;
         g.klen = g.kpad = conv_rgb_klen(kh);
@@ -301,10 +301,14 @@ __device__ __forceinline__ void pack_range(const float* __restrict__ w, T* __res
         float v = 0.f;
         if (mode == STMI_PACK_FWD_ROWOUT) {
             if (row < g.rows && e < g.klen) v = w[(((long)t * kw + row / co) * ci + e) * co + row % co];
-        } else if (mode == STMI_PACK_FWD_RGB) {
+        } else if (mode == STMI_PACK_FWD_RGB || mode == STMI_PACK_DGRAD_RGB) {
             const int run = 4 * (kw + 1);
             const int ky = e / run, r = e - ky * run, kx = r >> 2, c = r & 3;
-            if (row < g.rows && ky < kh && kx < kw && c < ci) v = w[(((long)ky * kw + kx) * ci + c) * co + row];
+            if (row < g.rows && ky < kh && kx < kw && c < 3) {
+                // backward-data: the flipped kernel with its channel axes exchanged (row = ci, c = co)
+                v = mode == STMI_PACK_FWD_RGB ? w[(((long)ky * kw + kx) * ci + c) * co + row]
+                                              : w[(((long)(kh - 1 - ky) * kw + (kw - 1 - kx)) * ci + row) * co + c];
+            }
         } else if (row < g.rows && e < g.klen) {
             int ky, kx, kc;
             const int kch = mode == STMI_PACK_FWD ? ci : co;

@@ -23,8 +23,10 @@ namespace {
 constexpr int kRgbPH = 8, kRgbPW = 32;  // output pixels per block: 4 waves x (2 rows x 32)
 }
 
-template <typename T, int K, int TC>
-__global__ __launch_bounds__(256) void conv_rgb_kernel(const float* __restrict__ x, float scale, const float* mean,
+// XT: element type of the image, float (forward layers) or T (backward-data of a layer that WRITES 3
+// channels: its input gradient is this same convolution of dy with the flipped, transposed kernel).
+template <typename T, int K, int TC, typename XT>
+__global__ __launch_bounds__(256) void conv_rgb_kernel(const XT* __restrict__ x, float scale, const float* mean,
                                                        const T* __restrict__ wq, const ConvGemmParams p) {
     constexpr int EPC = 16 / (int)sizeof(T);     // elements per 16-byte K fragment
     constexpr int RUNPX = K + 1;                 // pixels per kernel-row run (K is odd)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const float* __restrict__
     }
     // patch -> LDS: fp32 image elements, preprocessed, converted; zeros outside the image and in channel 3
     {
-        const float* img = x + (long)n * H * W * 3;
+        const XT* img = x + (long)n * H * W * 3;
         float m3[3] = {0.f, 0.f, 0.f};
         if (mean) { m3[0] = mean[0]; m3[1] = mean[1]; m3[2] = mean[2]; }
         for (int i = tid; i < PHH * PWH; i += 256) {
@@ -67,10 +69,10 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const float* __restrict__
             const int iy = ty0 - PAD + r, ix = tx0 - PAD + c;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const float* s = img + ((long)iy * W + ix) * 3;
-                v[0] = s[0] * scale - m3[0];
-                v[1] = s[1] * scale - m3[1];
-                v[2] = s[2] * scale - m3[2];
+                const XT* s = img + ((long)iy * W + ix) * 3;
+                v[0] = to_f32<XT>(s[0]) * scale - m3[0];
+                v[1] = to_f32<XT>(s[1]) * scale - m3[1];
+                v[2] = to_f32<XT>(s[2]) * scale - m3[2];
             }
             T* d = reinterpret_cast<T*>(pl + (r * PWH + c) * PIX_B);
 #pragma unroll
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 int conv_rgb_klen(int k) { return (4 * k * (k + 1) + 31) / 32 * 32; }
 
-template <typename T, int K, int TC>
-static int launch_rgb(const float* x, float scale, const float* mean, const void* wq, const ConvGemmParams& p,
+template <typename T, int K, int TC, typename XT>
+static int launch_rgb(const XT* x, float scale, const float* mean, const void* wq, const ConvGemmParams& p,
                       hipStream_t s) {
     constexpr int KL = (4 * K * (K + 1) + 31) / 32 * 32;
     constexpr int CO = 16 * TC;
@@ -143,7 +145,7 @@ static int launch_rgb(const float* x, float scale, const float* mean, const void
     constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_BYTES ? W_BYTES + P_BYTES : S_BYTES) + 15) / 16 * 16;
     static bool attr_set = false;  // idempotent; a racing second call is harmless
     if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC, XT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_rgb_kernel)");
         if (rc) return rc;
@@ -151,14 +153,16 @@ static int launch_rgb(const float* x, float scale, const float* mean, const void
     }
     {
         char name[160];
-        snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d>(float const*, float, float const*, %s const*, stmi::ConvGemmParams)",
-                 sizeof(T) == 2 ? "__bf16" : "float", K, TC, sizeof(T) == 2 ? "__bf16" : "float");
+        const char* tn = sizeof(T) == 2 ? "__bf16" : "float";
+        const char* xn = sizeof(XT) == 2 ? "__bf16" : "float";
+        snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d, %s>(%s const*, float, float const*, %s const*, stmi::ConvGemmParams)",
+                 tn, K, TC, xn, xn, tn);
         set_last_conv_kernel(name);
     }
     const long tiles = (long)p.N * ceil_div(p.Hi, kRgbPH) * ceil_div(p.Wi, kRgbPW);
     if (tiles <= 0) return STMI_OK;
     STMI_REQUIRE(tiles < (1L << 31), "conv_rgb: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_rgb_kernel<T, K, TC>), dim3((unsigned)tiles), dim3(256), kLds, s, x, scale, mean, (const T*)wq, p);
+    hipLaunchKernelGGL((conv_rgb_kernel<T, K, TC, XT>), dim3((unsigned)tiles), dim3(256), kLds, s, x, scale, mean, (const T*)wq, p);
     STMI_LAUNCH_CHECK("conv_rgb_kernel");
     return STMI_OK;
 }
@@ -175,10 +179,31 @@ int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void
     STMI_REQUIRE((long)n * h * w * 3 < (1L << 31), "conv_rgb: image batch too large for 32-bit indexing");
     p.row_store_ok = 1;
     const bool bf = dtype == STMI_BF16;
-    if (k == 9 && co == 32) return bf ? launch_rgb<bf16_t, 9, 2>(x, scale, mean, wq, p, s) : launch_rgb<float, 9, 2>(x, scale, mean, wq, p, s);
-    if (k == 3 && co == 64) return bf ? launch_rgb<bf16_t, 3, 4>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 4>(x, scale, mean, wq, p, s);
-    if (k == 3 && co == 32) return bf ? launch_rgb<bf16_t, 3, 2>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 2>(x, scale, mean, wq, p, s);
+    if (k == 9 && co == 32) return bf ? launch_rgb<bf16_t, 9, 2, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 9, 2, float>(x, scale, mean, wq, p, s);
+    if (k == 3 && co == 64) return bf ? launch_rgb<bf16_t, 3, 4, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 4, float>(x, scale, mean, wq, p, s);
+    if (k == 3 && co == 32) return bf ? launch_rgb<bf16_t, 3, 2, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 2, float>(x, scale, mean, wq, p, s);
     set_error("conv_rgb: unsupported (k, co) = (%d, %d); built for (9, 32), (3, 64) and (3, 32)", k, co);
+    return STMI_ERR_INVALID;
+}
+
+// Backward-data of a k x k stride-1 SAME convolution ci -> 3 (the stylizer's last layer,
+// full_graph_stylizer_network.py:78): dx[n,h,w,ci] = conv(dy[n,h,w,3], flipped and transposed kernel),
+// the weights packed with STMI_PACK_DGRAD_RGB.
+int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
+                        hipStream_t s) {
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.out = dx; p.alpha = 1.f;
+    p.N = n; p.Hi = h; p.Wi = w; p.Ci = 3;
+    p.Ho = h; p.Wo = w; p.Co = ci;
+    STMI_REQUIRE((((uintptr_t)dx | (uintptr_t)wq) & 15) == 0, "conv_rgb dgrad: dx and the packed weights must be 16-byte aligned");
+    STMI_REQUIRE((long)n * h * w * 3 < (1L << 31), "conv_rgb dgrad: gradient batch too large for 32-bit indexing");
+    p.row_store_ok = 1;
+    if (k == 9 && ci == 32) {
+        return dtype == STMI_BF16 ? launch_rgb<bf16_t, 9, 2, bf16_t>((const bf16_t*)dy, 1.f, nullptr, wq, p, s)
+                                  : launch_rgb<float, 9, 2, float>((const float*)dy, 1.f, nullptr, wq, p, s);
+    }
+    set_error("conv_rgb dgrad: unsupported (k, ci) = (%d, %d); built for (9, 32)", k, ci);
     return STMI_ERR_INVALID;
 }
 

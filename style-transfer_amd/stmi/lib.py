@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, '..', 'libstmi355.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-PACK_FWD, PACK_DGRAD, PACK_FWD_ROWOUT, PACK_FWD_RGB = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD, PACK_FWD_ROWOUT, PACK_FWD_RGB, PACK_DGRAD_RGB = 0, 1, 2, 3, 4
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -28,6 +28,7 @@ SIGNATURES = {
     'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_rgb_nhwc_fwd': (_c_int, [_vp, _c_float] + [_vp] * 5 + [_c_int] * 7 + [_vp]),
+    'stmi_conv2d_rgb_nhwc_dgrad': (_c_int, [_vp] * 3 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_fwd': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),

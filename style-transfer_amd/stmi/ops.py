@@ -8,7 +8,7 @@ Tensors are NHWC, contiguous, on the current HIP device, float32 or bfloat16.
 import torch
 
 from . import lib as _lib
-from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_FWD, PACK_FWD_RGB, PACK_FWD_ROWOUT  # noqa: F401
+from .lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PACK_DGRAD, PACK_DGRAD_RGB, PACK_FWD, PACK_FWD_RGB, PACK_FWD_ROWOUT  # noqa: F401
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -148,6 +148,20 @@ def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=Non
                                             y.data_ptr(), _ptr(pre), n, h, w, co, k, int(relu), _dt(y)),
                co, n * h * w, 3, k * k, 1)
     return (y, pre) if want_pre else y
+
+
+def conv2d_rgb_dgrad(dy, w_packed, k, ci, out=None):
+    """Gradient w.r.t. the input of a k x k stride-1 conv ci -> 3: dy [n,h,w,3] -> dx [n,h,w,ci];
+    w_packed: the [k,k,ci,3] weight packed with PACK_DGRAD_RGB."""
+    n, h, w, c = dy.shape
+    assert c == 3 and (k, ci) in RGB_CONFIGS[:1], (c, k, ci)
+    _chk(dy, 'dy')
+    _chk(w_packed, 'w_packed', dy.dtype, (packed_elems(k, k, ci, 3, PACK_DGRAD_RGB),))
+    oshape = (n, h, w, ci)
+    dx = torch.empty(oshape, dtype=dy.dtype, device=dy.device) if out is None else _chk(out, 'out', dy.dtype, oshape)
+    _conv_call('stmi_conv2d_rgb_nhwc_dgrad', (dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), n, h, w, ci, k, _dt(dy)),
+               ci, n * h * w, 3, k * k, 1)
+    return dx
 
 
 def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None):

@@ -106,6 +106,10 @@ class StylizerNet:
             b.rgb = b.rows == 'in' and (k, co) in ops.RGB_CONFIGS and 'r' not in _SERIAL
             if b.rgb:
                 fwd_mode = ops.PACK_FWD_RGB
+            # ... and the backward-data of the 3-channel LAST layer is that same kernel on dy
+            b.rgb_bwd = b.rows == 'out' and co == 3 and (k, c) in ops.RGB_CONFIGS[:1] and 'r' not in _SERIAL
+            if b.rgb_bwd:
+                bwd_mode = ops.PACK_DGRAD_RGB
             if b.rows:
                 b.pad_left = (k - 1) // 2
                 b.rows_buf = (torch.empty((batch, h, w, 32), dtype=dtype, device=device)
@@ -288,6 +292,11 @@ class StylizerNet:
                         ops.pixels_to_rows(self.x_in, b.k, -b.pad_left, out=b.rows_buf)
                     ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
+            elif b.rows == 'out' and b.rgb_bwd:   # row patches of dconv: for the weight gradient only
+                def wgrad():
+                    rg = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
+                    ops.conv2d_wgrad(x_in, rg, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
+                    ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             elif b.rows == 'out':
                 rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
 
@@ -305,6 +314,9 @@ class StylizerNet:
             addend = pending_skip if b.role == 'a' else None
             if b.kind == 'deconv':
                 ops.conv2d_transpose_dgrad(dconv, b.wp_bwd, b.kshape, b.s, addend=addend, out=dx)
+            elif b.rgb_bwd:
+                assert addend is None
+                ops.conv2d_rgb_dgrad(dconv, b.wp_bwd, b.k, b.ci, out=dx)
             elif rows_g is not None:
                 ops.conv2d_dgrad(rows_g, b.wp_bwd, (b.k, 1, b.ci, 32), 1, (b.in_h, b.in_w), addend=addend, out=dx)
             else:

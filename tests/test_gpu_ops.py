@@ -136,6 +136,23 @@ def test_conv_rgb_matches_preprocess_then_conv(cuda, dtype, case):
     assert 'conv_rgb_kernel' in ops.last_conv_kernel()
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 24, 40), (1, 37, 45), (4, 256, 256)])
+def test_conv_rgb_dgrad_is_the_gradient_of_the_three_channel_output_layer(cuda, dtype, shape):
+    from stmi import ops
+    n, h, w = shape
+    k, ci = 9, 32
+    x = rnd((n, h, w, ci), 1)
+    wt = rnd((k, k, ci, 3), 2, 1.0 / np.sqrt(k * k * ci))
+    dy = rnd((n, h, w, 3), 3)
+    xq = q(x, dtype).requires_grad_()
+    y = O.conv2d_same(xq, q(wt, dtype), 1)
+    (gx,) = torch.autograd.grad(y, xq, q(dy, dtype))
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD_RGB, dtype)
+    dx = ops.conv2d_rgb_dgrad(dy.to(cuda, dtype), wp, k, ci)
+    assert rel_err(dx, gx) <= TOL[dtype]
+
+
 DECONV_CASES = [(2, 6, 5, 128, 64, 3, 2), (1, 7, 8, 64, 32, 3, 2), (1, 4, 4, 16, 8, 3, 2)]
 
 
