@@ -100,6 +100,16 @@ int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean,
                              const float* bias, void* y, void* y_pre,
                              int n, int h, int w, int co, int k, int relu, int dtype, void* stream);
 
+/* k x k stride-1 SAME convolution ci -> 3 in one launch (the stylizer's last layer,
+ * full_graph_stylizer_network.py:78; with the flipped, transposed kernel it is the backward-data of VGG
+ * conv1_1): x [n,h,w,ci] -> y [n,h,w,3] = conv(x) + addend (optional, shaped like y).  W packed with
+ * STMI_PACK_FWD_ROWOUT; same values as stmi_conv2d_nhwc_fwd on those weights followed by
+ * stmi_rows_to_pixels_sum, except that the intermediate stays in fp32.  stmi_conv2d_to3_supported
+ * returns 1 for the (k, ci, dtype) it is built for: (9, 32), (3, 32) in both dtypes, (3, 64) in bf16. */
+int stmi_conv2d_to3_supported(int k, int ci, int dtype);
+int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const void* addend, void* y,
+                             int n, int h, int w, int ci, int k, int dtype, void* stream);
+
 /* Gradient w.r.t. the input of a k x k stride-1 convolution that WRITES three channels (the stylizer's
  * last layer, full_graph_stylizer_network.py:78): dy [n,h,w,3] in dtype -> dx [n,h,w,ci]; W packed with
  * STMI_PACK_DGRAD_RGB.  Built for (k, ci) = (9, 32). */

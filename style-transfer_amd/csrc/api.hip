@@ -32,6 +32,9 @@ int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void
                       void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s);
 int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
                         hipStream_t s);
+int conv_to3_supported(int k, int ci, int dtype);
+int conv_to3_impl(const void* x, const void* wq, const void* addend, void* y, int n, int h, int w, int ci, int k,
+                  int dtype, hipStream_t s);
 int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
                     int stride, int accumulate, int dtype, hipStream_t s);
 int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s);
@@ -163,6 +166,16 @@ int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, v
     STMI_REQUIRE(dy && w_packed_dgrad_rgb && dx, "conv2d_rgb_nhwc_dgrad: null pointer");
     if (n == 0) return STMI_OK;
     return conv_rgb_dgrad_impl(dy, w_packed_dgrad_rgb, dx, n, h, w, ci, k, dtype, S(stream));
+}
+
+int stmi_conv2d_to3_supported(int k, int ci, int dtype) { return conv_to3_supported(k, ci, dtype); }
+
+int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const void* addend, void* y, int n, int h,
+                             int w, int ci, int k, int dtype, void* stream) {
+    if (check_conv("conv2d_to3_nhwc_fwd", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_rowout && y, "conv2d_to3_nhwc_fwd: null pointer");
+    if (n == 0) return STMI_OK;
+    return conv_to3_impl(x, w_packed_rowout, addend, y, n, h, w, ci, k, dtype, S(stream));
 }
 
 int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,

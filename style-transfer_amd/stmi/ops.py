@@ -150,6 +150,25 @@ def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=Non
     return (y, pre) if want_pre else y
 
 
+def to3_supported(k, ci, dtype):
+    return bool(_lib.load().stmi_conv2d_to3_supported(k, ci, _DT[dtype]))
+
+
+def conv2d_to3(x, w_packed, k, addend=None, out=None):
+    """k x k stride-1 SAME conv ci -> 3 in one launch: conv2d_fwd with PACK_FWD_ROWOUT weights and
+    rows_to_pixels_sum fused (the (kx, co) intermediate stays in LDS, in fp32)."""
+    n, h, w, ci = x.shape
+    _chk(x, 'x')
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(k, k, ci, 3, PACK_FWD_ROWOUT),))
+    oshape = (n, h, w, 3)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    if addend is not None:
+        _chk(addend, 'addend', x.dtype, oshape)
+    _conv_call('stmi_conv2d_to3_nhwc_fwd', (x.data_ptr(), w_packed.data_ptr(), _ptr(addend), y.data_ptr(), n, h, w, ci, k,
+                                            _dt(x)), 3, n * h * w, ci, k * k, 1)
+    return y
+
+
 def conv2d_rgb_dgrad(dy, w_packed, k, ci, out=None):
     """Gradient w.r.t. the input of a k x k stride-1 conv ci -> 3: dy [n,h,w,3] -> dx [n,h,w,ci];
     w_packed: the [k,k,ci,3] weight packed with PACK_DGRAD_RGB."""

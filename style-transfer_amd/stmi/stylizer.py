@@ -110,10 +110,12 @@ class StylizerNet:
             b.rgb_bwd = b.rows == 'out' and co == 3 and (k, c) in ops.RGB_CONFIGS[:1] and 'r' not in _SERIAL
             if b.rgb_bwd:
                 bwd_mode = ops.PACK_DGRAD_RGB
+            # ... and the forward of that layer has a one-launch kernel that folds the row patches in LDS
+            b.to3 = b.rows == 'out' and co == 3 and ops.to3_supported(k, c, dtype) and 'r' not in _SERIAL
             if b.rows:
                 b.pad_left = (k - 1) // 2
-                b.rows_buf = (torch.empty((batch, h, w, 32), dtype=dtype, device=device)
-                              if training or not b.rgb else None)
+                need_rows = (training or not b.rgb) if b.rows == 'in' else not b.to3
+                b.rows_buf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if need_rows else None
                 if training:
                     b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
                                          device=device)
@@ -204,6 +206,8 @@ class StylizerNet:
             elif b.rows == 'in':
                 ops.pixels_to_rows(cur, b.k, -b.pad_left, out=b.rows_buf)
                 ops.conv2d_fwd(b.rows_buf, b.wp_fwd, (b.k, 1, 32, b.co), 1, out=conv_out)
+            elif b.rows == 'out' and b.to3:
+                ops.conv2d_to3(cur, b.wp_fwd, b.k, out=conv_out)
             elif b.rows == 'out':
                 ops.conv2d_fwd(cur, b.wp_fwd, (b.k, 1, b.ci, 32), 1, out=b.rows_buf)
                 ops.rows_to_pixels_sum(b.rows_buf, b.co, b.k, -b.pad_left, out=conv_out)

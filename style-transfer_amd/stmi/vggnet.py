@@ -295,8 +295,12 @@ class VggReplica:
                 if in_name is None and L.rows:
                     # d(preprocess)/dx = 255/2 is in the weights; the TV gradient joins in the row sum
                     k, ci = L.kshape[0], L.kshape[2]
-                    ops.conv2d_fwd(g, L.wp_bwd_rows, (k, 1, L.kshape[3], 32), 1, out=self.rows_gbuf)
-                    ops.rows_to_pixels_sum(self.rows_gbuf, ci, k, -((k - 1) // 2), out=self.d_image, addend=self.tv_grad)
+                    if ci == 3 and ops.to3_supported(k, L.kshape[3], net.dtype) and 'r' not in _SERIAL:
+                        ops.conv2d_to3(g, L.wp_bwd_rows, k, addend=self.tv_grad, out=self.d_image)
+                    else:
+                        ops.conv2d_fwd(g, L.wp_bwd_rows, (k, 1, L.kshape[3], 32), 1, out=self.rows_gbuf)
+                        ops.rows_to_pixels_sum(self.rows_gbuf, ci, k, -((k - 1) // 2), out=self.d_image,
+                                               addend=self.tv_grad)
                     g = self.d_image
                 elif in_name is None:
                     # d(preprocess)/dx = 255/2; the TV gradient joins here

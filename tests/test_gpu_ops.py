@@ -153,6 +153,31 @@ def test_conv_rgb_dgrad_is_the_gradient_of_the_three_channel_output_layer(cuda, 
     assert rel_err(dx, gx) <= TOL[dtype]
 
 
+TO3_CASES = [(2, 24, 40, 9, 32, False), (1, 37, 45, 9, 32, False), (4, 256, 256, 9, 32, False),
+             (2, 16, 60, 3, 64, True), (1, 21, 50, 3, 32, True), (1, 8, 30, 3, 32, False)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', TO3_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_to3_matches_the_convolution(cuda, dtype, case):
+    """One-launch ci -> 3 convolution (row patches on the output side, folded in LDS) against the
+    oracle's convolution, with the optional addend and tiles clipped at both borders."""
+    from stmi import ops
+    n, h, w, k, ci, with_addend = case
+    if not ops.to3_supported(k, ci, dtype):
+        pytest.skip('no instantiation for this (k, ci, dtype): the caller keeps the two-launch path')
+    x = rnd((n, h, w, ci), 1)
+    wt = rnd((k, k, ci, 3), 2, 1.0 / np.sqrt(k * k * ci))
+    add = rnd((n, h, w, 3), 3) if with_addend else None
+    ref = O.conv2d_same(q(x, dtype), q(wt, dtype), 1)
+    if add is not None:
+        ref = ref + q(add, dtype)
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD_ROWOUT, dtype)
+    y = ops.conv2d_to3(x.to(cuda, dtype), wp, k, addend=None if add is None else add.to(cuda, dtype))
+    assert rel_err(y, ref) <= TOL[dtype]
+    assert 'conv_to3_kernel' in ops.last_conv_kernel()
+
+
 DECONV_CASES = [(2, 6, 5, 128, 64, 3, 2), (1, 7, 8, 64, 32, 3, 2), (1, 4, 4, 16, 8, 3, 2)]
 
 
