@@ -217,41 +217,64 @@ int mse_impl(const void* a, const void* b, void* grad, float* loss, float loss_s
 
 // Gram form: g fp32 [n,c,c] against target fp32 [c,c]; writes the scaled
 // difference into the K-contiguous padded layout the Gram-backward GEMM reads
-// ([n][rows_pad][kpad], zero padding).
-template <typename T>
+// ([n][rows_pad][kpad], zero padding).  (dG + dG^T)/2 needs the transposed element as well: a
+// block owns a TS x TS tile, brings the mirrored tile's differences through LDS (both tiles are
+// read along their rows), and ends with one atomic on the loss.
+template <typename T, int TS>
 __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__ g, const float* __restrict__ target,
                                                        T* __restrict__ sout, float* loss, float loss_scale,
                                                        float grad_scale, int n, int c, int rows_pad, int kpad) {
     __shared__ float red[4];
+    __shared__ float mir[TS][TS + 1];
+    const int tiles_c = kpad / TS, tiles_r = (rows_pad + TS - 1) / TS;
+    int t = blockIdx.x;
+    const int b = t / (tiles_r * tiles_c);
+    t -= b * tiles_r * tiles_c;
+    const int row0 = (t / tiles_c) * TS, col0 = (t % tiles_c) * TS;
+    const float* gb = g + (long)b * c * c;
+    // mirrored tile: element (col0 + i, row0 + j), read along j
+    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+        const int i = e / TS, j = e - i * TS;
+        const int r = col0 + i, q = row0 + j;
+        mir[i][j] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
+    }
+    __syncthreads();
     float acc = 0.f;
-    // a block walks whole packed rows: 32-bit index arithmetic, no per-element division
-    for (int br = blockIdx.x; br < n * rows_pad; br += gridDim.x) {
-        const int b = br / rows_pad, row = br - b * rows_pad;
-        const float* gb = g + (long)b * c * c;
-        T* so = sout + (long)br * kpad;
-        for (int col = threadIdx.x; col < kpad; col += 256) {
-            float v = 0.f;
-            if (row < c && col < c) {
-                const float d = gb[row * c + col] - target[row * c + col];
-                const float dt = gb[col * c + row] - target[col * c + row];
-                acc += d * d;
-                v = grad_scale * 0.5f * (d + dt);  // (dG + dG^T)/2: exact also for a non-symmetric target
-            }
-            so[col] = from_f32<T>(v);
+    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+        const int i = e / TS, j = e - i * TS;
+        const int row = row0 + i, col = col0 + j;
+        if (row >= rows_pad) continue;
+        float v = 0.f;
+        if (row < c && col < c) {
+            const float d = gb[row * c + col] - target[row * c + col];
+            acc += d * d;
+            v = grad_scale * 0.5f * (d + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
         }
+        sout[((long)b * rows_pad + row) * kpad + col] = from_f32<T>(v);
     }
     const float tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
 }
 
+template <typename T>
+static void launch_gram_mse(const float* g, const float* target, void* sout, float* loss, float loss_scale,
+                            float grad_scale, int n, int c, int rows_pad, int kpad, hipStream_t s) {
+    // 64 x 64 tiles when the padded matrix is made of them (at most 256 blocks, i.e. same-address atomics, for
+    // the 512-channel Grams of a batch of 4); 32 x 32 for the small ones
+    if (rows_pad % 64 == 0 && kpad % 64 == 0) {
+        const dim3 grid(n * (rows_pad / 64) * (kpad / 64));
+        hipLaunchKernelGGL((gram_mse_kernel<T, 64>), grid, dim3(256), 0, s, g, target, (T*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+    } else {
+        const dim3 grid(n * ((rows_pad + 31) / 32) * (kpad / 32));
+        hipLaunchKernelGGL((gram_mse_kernel<T, 32>), grid, dim3(256), 0, s, g, target, (T*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+    }
+}
+
 int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, float loss_scale, float grad_scale,
                   int n, int c, int dtype, hipStream_t s) {
     const int rows_pad = packed_rows(c), kpad = round_up(c, 32);
-    const dim3 grid(n * rows_pad < 256 ? n * rows_pad : 256);  // few blocks: one same-address atomic each
-    if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(gram_mse_kernel<bf16_t>, grid, dim3(256), 0, s, g, target, (bf16_t*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
-    else
-        hipLaunchKernelGGL(gram_mse_kernel<float>, grid, dim3(256), 0, s, g, target, (float*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+    if (dtype == STMI_BF16) launch_gram_mse<bf16_t>(g, target, sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
+    else launch_gram_mse<float>(g, target, sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
     STMI_LAUNCH_CHECK("gram_mse_kernel");
     return STMI_OK;
 }
