@@ -19,8 +19,22 @@ from . import ops
 from .stylizer import StylizerNet
 from .vggnet import VggFeatures, _SERIAL
 
-# block ranges (hi..lo) of the stylizer backward; one all-reduce bucket each
-BWD_SEGMENTS = [(15, 11), (10, 7), (6, 0)]
+import os
+
+
+def _segments(cuts):
+    """Block ranges (hi..lo) of the stylizer backward from the blocks each later range starts at."""
+    tops = [15] + sorted((int(c) - 1 for c in cuts), reverse=True)
+    los = [t + 1 for t in tops[1:]] + [0]
+    return list(zip(tops, los))
+
+
+# Block ranges (hi..lo) of the stylizer backward; one all-reduce bucket each, reduced while the next range
+# runs.  Every extra range costs about 47 us per step on one MI355X (a graph boundary, and the weight-gradient
+# branch drained at it), about what the all-reduce of a 3 MB bucket takes: two ranges (3.9 MB behind blocks
+# 15..7, 2.8 MB behind 6..0) overlap the larger bucket for the price of one boundary.  STMI_BWD_CUTS (tuning
+# aid) lists the first block of every range but the last one's: "7" (the default), "11,7", "" (one bucket).
+BWD_SEGMENTS = _segments([c for c in os.environ.get('STMI_BWD_CUTS', '7').split(',') if c.strip()])
 
 
 class GradBuckets:
