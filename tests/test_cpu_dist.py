@@ -69,7 +69,7 @@ def test_bucketed_allreduce_and_frame_sharding_world2():
     ranges = results[0][2]
     # the buckets, in the order backward finishes them, tile all 1,677,638 gradients
     assert len(ranges) >= 2 and ranges[0][1] == 1677638 and ranges[-1][0] == 0
-    assert sorted(ranges)[0][1] == sorted(ranges)[1][0] and sorted(ranges)[1][1] == sorted(ranges)[2][0]
+    assert all(a[1] == b[0] for a, b in zip(sorted(ranges), sorted(ranges)[1:]))
     frames = results[0][3] + results[1][3]
     assert sorted(frames) == list(range(37))                    # every frame exactly once, no exchange
     assert abs(len(results[0][3]) - len(results[1][3])) <= 1
