@@ -283,6 +283,13 @@ bool try_launch_conv_gemm_pc(const ConvGemmParams& p, int dtype, hipStream_t s, 
     const int rb = pc_row_bytes(p, dtype);
     if (rb == 0 || p.co_pad % 32 != 0 || getenv("STMI_NO_PC")) return false;
     if ((((uintptr_t)p.in | (uintptr_t)p.wp) & 15) != 0 || p.Ci % (dtype == STMI_BF16 ? 8 : 4) != 0) return false;
+    {
+        // A launch of fewer than five K steps is all prologue and epilogue: eight producer waves and a 4-deep
+        // ring bring nothing there, and the smaller blocks of the same-wave kernel hide more of the latency
+        // (Gram backward of the 64..256-channel taps: 60 -> 50 us per step).  STMI_PC_MIN_STEPS: tuning aid.
+        static const int min_steps = getenv("STMI_PC_MIN_STEPS") ? atoi(getenv("STMI_PC_MIN_STEPS")) : 5;
+        if (p.ntaps * (p.klen / (rb / (dtype == STMI_BF16 ? 2 : 4))) < min_steps) return false;
+    }
     *rc = dtype == STMI_BF16 ? launch_pc_typed<bf16_t>(p, rb, s, name, name_len, "__bf16")
                              : launch_pc_typed<float>(p, rb, s, name, name_len, "float");
     return true;
