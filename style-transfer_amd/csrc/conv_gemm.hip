@@ -221,15 +221,17 @@ static const char* kV1Cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4,
 // gather-GEMM for the other layers with a multiple of 64 bytes of K per tap (the same-wave LDS-DMA
 // kernel stays behind it as a tuning reference), register-staged gather-GEMM for the rest.
 // The name of the instantiation launched is kept per thread for profiling front ends.
+static void set_row_store(ConvGemmParams& p, int dtype) {
+    const int epc = dtype == STMI_BF16 ? 8 : 4;
+    const uintptr_t ptrs = (uintptr_t)p.out | (uintptr_t)p.out_pre | (uintptr_t)p.mask | (uintptr_t)p.addend;
+    p.row_store_ok = p.Co % epc == 0 && (ptrs & 15) == 0;
+}
+
 int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     int rc = STMI_OK;
     const char* tname = dtype == STMI_BF16 ? "__bf16" : "float";
     ConvGemmParams p = p_in;
-    {
-        const int epc = dtype == STMI_BF16 ? 8 : 4;
-        const uintptr_t ptrs = (uintptr_t)p.out | (uintptr_t)p.out_pre | (uintptr_t)p.mask | (uintptr_t)p.addend;
-        p.row_store_ok = p.Co % epc == 0 && (ptrs & 15) == 0;
-    }
+    set_row_store(p, dtype);
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_pc(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) {
@@ -449,7 +451,48 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
         }
         return launch_conv_gemm(p, dtype, s);
     }
-    // one launch per output parity class: input row = (iy + pt - ky) / stride must be integral
+    // Output parity classes: input row = (iy + pt - ky) / stride must be integral, so class (cy, cx) uses the
+    // taps with ky = cy + pt, kx = cx + pl (mod stride).  First try all classes in ONE launch of the
+    // producer/consumer kernel (each is only 1..4 taps deep: four launches are mostly launch overhead).
+    if (stride * stride <= 4) {
+        ConvGemmParams m = p;
+        m.oys = stride; m.oxs = stride;
+        int nt = 0, nc = 0, most = 0;
+        bool fits = true;
+        for (int cy = 0; cy < stride && fits; cy++) {
+            for (int cx = 0; cx < stride && fits; cx++) {
+                const int hs = (h - cy + stride - 1) / stride, ws = (w - cx + stride - 1) / stride;
+                if (hs <= 0 || ws <= 0) continue;
+                ConvGemmParams::SubGrid& g2 = m.cls[nc];
+                g2.Hs = hs; g2.Ws = ws; g2.oy0 = cy; g2.ox0 = cx; g2.tap0 = nt; g2.ntaps = 0; g2.tile_end = 0;
+                for (int ky = 0; ky < kh; ky++) {
+                    const int ny = cy + pt - ky;
+                    if (((ny % stride) + stride) % stride) continue;
+                    for (int kx = 0; kx < kw; kx++) {
+                        const int nx = cx + pl - kx;
+                        if (((nx % stride) + stride) % stride) continue;
+                        if (nt >= kMaxTaps) { fits = false; break; }
+                        m.taps[nt].dy = (short)((ny - (((ny % stride) + stride) % stride)) / stride);
+                        m.taps[nt].dx = (short)((nx - (((nx % stride) + stride) % stride)) / stride);
+                        m.taps[nt].widx = ky * kw + kx;
+                        nt++;
+                        g2.ntaps++;
+                    }
+                }
+                if (g2.ntaps == 0) { fits = false; break; }   // a class without taps is all zeros: leave it to the loop below
+                if (g2.ntaps > most) { most = g2.ntaps; m.Hs = hs; m.Ws = ws; }
+                nc++;
+            }
+        }
+        if (fits && nc > 0) {
+            m.nclasses = nc;
+            m.ntaps = most;
+            set_row_store(m, dtype);
+            int rc = STMI_OK;
+            if (try_launch_conv_gemm_pc_multi(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+        }
+    }
+    // one launch per class
     for (int cy = 0; cy < stride; cy++) {
         for (int cx = 0; cx < stride; cx++) {
             p.oy0 = cy; p.ox0 = cx; p.oys = stride; p.oxs = stride;

@@ -23,6 +23,16 @@ struct ConvGemmParams {
     int row_store_ok;  // Co and the tensors' alignment allow whole-row 16-byte stores (set by the launcher)
     unsigned pt_div[3], pt_magic[3];  // patch kernel: channel tiles, tiles per row, tile rows per image (+ reciprocals)
     Tap taps[kMaxTaps];
+    // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
+    // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the
+    // only sub-grid.  Otherwise class c covers block tiles [cls[c-1].tile_end, cls[c].tile_end), has its own
+    // sub-grid and uses taps[tap0 .. tap0 + ntaps) of the shared table.
+    struct SubGrid {
+        int Hs, Ws, oy0, ox0, ntaps, tap0;
+        unsigned tile_end;
+    };
+    int nclasses;
+    SubGrid cls[4];
 };
 
 // Epilogue shared by the kernels.  Accumulator tile (tc, tp) of a wave holds, in lane
@@ -253,6 +263,8 @@ const char* conv_gemm_glds_cfg_name(const ConvGemmParams& p, int dtype);
 // Returns true and launches when the problem fits it; name (optional) receives the kernel's
 // name as a profiler prints it.
 bool try_launch_conv_gemm_pc(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
+// The same for p.nclasses > 0 sub-grids in one launch (fills in cls[].tile_end); false when it does not fit.
+bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
 // 3x3 stride-1 kernel with the input patch resident in LDS (conv_patch.hip).  Returns true
 // and launches when the problem fits it; name (optional) receives the kernel's name as a

@@ -70,9 +70,6 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int HWs = p.Hs * p.Ws;
-    const bool batched = p.w_batch_stride != 0;
-    const long Mz = batched ? (long)HWs : (long)p.N * HWs;
     // Blocks b and b+8 run on the same XCD: hand each XCD one contiguous run of tiles
     // (channel tile fastest, then pixels, then sample), so that the pixel rows it gathers
     // stay inside that XCD's own 4 MiB L2.
@@ -82,6 +79,18 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
         const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
         tile = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
     }
+    // sub-grid of this block (one launch may cover several, see ConvGemmParams::SubGrid)
+    int Hs = p.Hs, Ws = p.Ws, oy0 = p.oy0, ox0 = p.ox0, ntaps = p.ntaps, tap0 = 0;
+    if (p.nclasses > 0) {
+        int c = 0;
+        while (c + 1 < p.nclasses && tile >= p.cls[c].tile_end) c++;
+        Hs = p.cls[c].Hs; Ws = p.cls[c].Ws; oy0 = p.cls[c].oy0; ox0 = p.cls[c].ox0;
+        ntaps = p.cls[c].ntaps; tap0 = p.cls[c].tap0;
+        if (c > 0) tile -= p.cls[c - 1].tile_end;
+    }
+    const int HWs = Hs * Ws;
+    const bool batched = p.w_batch_stride != 0;
+    const long Mz = batched ? (long)HWs : (long)p.N * HWs;
     const unsigned n_co = p.co_pad / BLK_CO;
     const unsigned n_pix = (unsigned)((Mz + BLK_PIX - 1) / BLK_PIX);
     const int co0 = (tile % n_co) * BLK_CO;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
     const int z = tile_p / n_pix;
     const long zoff = batched ? (long)z * HWs : 0;
     const int ksteps = p.klen / BK;
-    const int nsteps = p.ntaps * ksteps;
+    const int nsteps = ntaps * ksteps;
 
     f32x4 acc[TC][TP];
 #pragma unroll
@@ -116,9 +125,9 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
                 const long mm = m + zoff;
                 const int n = (int)(mm / HWs);
                 const int rem = (int)(mm - (long)n * HWs);
-                const int i = rem / p.Ws;
+                const int i = rem / Ws;
                 py[j] = i * p.in_stride;
-                px[j] = (rem - i * p.Ws) * p.in_stride;
+                px[j] = (rem - i * Ws) * p.in_stride;
                 pbase[j] = (((long)n * p.Hi + py[j]) * p.Wi + px[j]) * p.Ci + (pos ^ row_swz<RB>(row)) * EPC;
             } else {
                 py[j] = -(1 << 20);
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
             constexpr int NI = NPX + (HAS_W ? NWX : 0);
             auto stage_next = [&](int slot) {
                 const unsigned base = lds_base + slot * SLOT;
-                const Tap tap = p.taps[st_t];
+                const Tap tap = p.taps[tap0 + st_t];
                 const int k0 = st_k * BK;
                 if (HAS_W) {
                     const T* wsrc = wp + ((long)tap.widx * p.co_pad + co0) * p.kpad + k0;
@@ -211,10 +220,10 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
             const long mm = m + zoff;
             const int n = (int)(mm / HWs);
             const int rem = (int)(mm - (long)n * HWs);
-            const int i = rem / p.Ws, j = rem - i * p.Ws;
-            return (((long)n * p.Ho + (p.oy0 + p.oys * i)) * p.Wo + (p.ox0 + p.oxs * j)) * p.Co;
+            const int i = rem / Ws, j = rem - i * Ws;
+            return (((long)n * p.Ho + (oy0 + p.oys * i)) * p.Wo + (ox0 + p.oxs * j)) * p.Co;
         });
-    } else if (wave < 4) {
+    } else if (wave < 4) {  // single sub-grid only (the launcher merges sub-grids only for row-wise stores)
         conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wave >> 1, wave & 1, lane >> 4, lane & 15, Mz, zoff, HWs);
     }
 }
@@ -236,8 +245,19 @@ static long pc_tiles(const ConvGemmParams& p, int blk_co, int blk_pix) {
     return (long)ceil_div(Mz, blk_pix) * (p.co_pad / blk_co) * (batched ? p.N : 1);
 }
 
+// Fills in the tile ranges of the sub-grids of a merged launch; returns the total.
+static long pc_assign_tiles(ConvGemmParams& p, int blk_co, int blk_pix) {
+    long total = 0;
+    for (int c = 0; c < p.nclasses; c++) {
+        total += (long)ceil_div((long)p.N * p.cls[c].Hs * p.cls[c].Ws, blk_pix) * (p.co_pad / blk_co);
+        p.cls[c].tile_end = (unsigned)total;
+    }
+    return total;
+}
+
 template <typename T, int TC, int TP, int RB>
-static int launch_pc(const ConvGemmParams& p, hipStream_t s, char* name, int name_len, const char* tname) {
+static int launch_pc(const ConvGemmParams& p_in, hipStream_t s, char* name, int name_len, const char* tname) {
+    ConvGemmParams p = p_in;
     constexpr size_t kLds = (size_t)kRing * (32 * TC + 32 * TP) * RB;
     static bool attr_set = false;  // idempotent; a racing second call is harmless
     if (!attr_set) {
@@ -249,7 +269,7 @@ static int launch_pc(const ConvGemmParams& p, hipStream_t s, char* name, int nam
     }
     if (name)
         snprintf(name, name_len, "void stmi::conv_gemm_pc_kernel<%s, %d, %d, %d>(stmi::ConvGemmParams)", tname, TC, TP, RB);
-    const long tiles = pc_tiles(p, 32 * TC, 32 * TP);
+    const long tiles = p.nclasses > 0 ? pc_assign_tiles(p, 32 * TC, 32 * TP) : pc_tiles(p, 32 * TC, 32 * TP);
     if (tiles <= 0) return STMI_OK;
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
     hipLaunchKernelGGL((conv_gemm_pc_kernel<T, TC, TP, RB>), dim3((unsigned)tiles), dim3(kThreads), kLds, s, p);
@@ -277,6 +297,18 @@ static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char*
     if (cfg == 1 && (p.co_pad % 128 != 0 || sizeof(T) == 4)) cfg = 2;  // the fp32 128 x 64 tile spills registers
     if (cfg == 1) return launch_pc<T, 4, 2, 128>(p, s, name, name_len, tname);
     return launch_pc<T, 2, 2, 128>(p, s, name, name_len, tname);
+}
+
+// Several sub-grids (p.nclasses > 0, p.cls[] filled in but for tile_end; p.Hs, p.Ws, p.ntaps describing the
+// largest of them, for the tile choice) in one launch.  Needs row-wise stores and one weight set.
+bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
+    const int rb = pc_row_bytes(p, dtype);
+    if (rb == 0 || p.co_pad % 32 != 0 || getenv("STMI_NO_PC") || getenv("STMI_NO_PC_MULTI")) return false;
+    if ((((uintptr_t)p.in | (uintptr_t)p.wp) & 15) != 0 || p.Ci % (dtype == STMI_BF16 ? 8 : 4) != 0) return false;
+    if (!p.row_store_ok || p.w_batch_stride != 0 || p.nclasses < 1 || p.nclasses > 4) return false;
+    *rc = dtype == STMI_BF16 ? launch_pc_typed<bf16_t>(p, rb, s, name, name_len, "__bf16")
+                             : launch_pc_typed<float>(p, rb, s, name, name_len, "float");
+    return true;
 }
 
 bool try_launch_conv_gemm_pc(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
