@@ -153,6 +153,33 @@ def test_conv_rgb_dgrad_is_the_gradient_of_the_three_channel_output_layer(cuda, 
     assert rel_err(dx, gx) <= TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 128, 64), (1, 9, 7, 64, 32), (1, 1, 5, 64, 64)])
+def test_parity_classes_in_one_launch_equal_one_launch_per_class(cuda, dtype, shape, monkeypatch):
+    """A stride-2 transposed convolution / backward-data runs its four output parity classes in one
+    launch; forcing one launch per class must give the same bits (also for odd sizes, where the
+    classes differ in size, and for a one-row image, where two of them are empty)."""
+    from stmi import ops
+    n, h, w, ci, co = shape
+    k, s = 3, 2
+    x = rnd((n, h, w, ci), 1).to(cuda, dtype)
+    wt = rnd((k, k, co, ci), 2, 1.0 / np.sqrt(k * k * ci)).to(cuda, torch.float32)
+    wp = ops.pack_conv_weights(wt, ops.PACK_DGRAD, dtype)
+    merged = ops.conv2d_transpose_fwd(x, wp, (k, k, co, ci), s)
+    monkeypatch.setenv('STMI_NO_PC_MULTI', '1')
+    per_class = ops.conv2d_transpose_fwd(x, wp, (k, k, co, ci), s)
+    assert torch.equal(merged, per_class)
+    # the same for the backward-data of a stride-2 convolution on an odd-sized input
+    hin, win = 2 * h - 1, 2 * w - 1
+    dy = rnd((n, h, w, co), 3).to(cuda, dtype)
+    w2 = rnd((k, k, ci, co), 4, 1.0 / np.sqrt(k * k * ci)).to(cuda, torch.float32)
+    wp2 = ops.pack_conv_weights(w2, ops.PACK_DGRAD, dtype)
+    a = ops.conv2d_dgrad(dy, wp2, (k, k, ci, co), s, (hin, win))
+    monkeypatch.delenv('STMI_NO_PC_MULTI')
+    b = ops.conv2d_dgrad(dy, wp2, (k, k, ci, co), s, (hin, win))
+    assert torch.equal(a, b)
+
+
 TO3_CASES = [(2, 24, 40, 9, 32, False), (1, 37, 45, 9, 32, False), (4, 256, 256, 9, 32, False),
              (2, 16, 60, 3, 64, True), (1, 21, 50, 3, 32, True), (1, 8, 30, 3, 32, False)]
 
