@@ -50,8 +50,10 @@ constexpr int kThreads = 64 * (4 + kProducers);
 
 }  // namespace
 
-// Block tile: 32*TC output channels x 32*TP pixels; RB bytes of K per row and step.
-template <typename T, int TC, int TP, int RB>
+// Block tile: 32*TC output channels x 32*TP pixels; RB bytes of K per row and step; RING slots of operand
+// tiles (4: three steps prefetched; 2: one, for launches of a few steps only, where the LDS goes into a wider
+// pixel tile instead: fewer blocks, each with the same fixed start and epilogue cost).
+template <typename T, int TC, int TP, int RB, int RING>
 __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = RB / (int)sizeof(T);  // K elements per step
@@ -165,17 +167,22 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
                 if (++st_k == ksteps) { st_k = 0; ++st_t; }
             };
 #pragma unroll
-            for (int s = 0; s < kRing - 1; s++)
+            for (int s = 0; s < RING - 1; s++)
                 if (s < nsteps) stage_next(s);
             for (int s = 0; s < nsteps; s++) {
-                // steps issued after s so far: min(nsteps - 1 - s, kRing - 2)
-                const int later = nsteps - 1 - s;
-                if (later >= 2) wait_vmcnt<2 * NI>();
-                else if (later >= 1) wait_vmcnt<NI>();
-                else wait_vmcnt<0>();
+                // steps issued after s so far: min(nsteps - 1 - s, RING - 2)
+                if constexpr (RING == 4) {
+                    const int later = nsteps - 1 - s;
+                    if (later >= 2) wait_vmcnt<2 * NI>();
+                    else if (later >= 1) wait_vmcnt<NI>();
+                    else wait_vmcnt<0>();
+                } else {
+                    static_assert(RING == 2, "ring depth");
+                    wait_vmcnt<0>();
+                }
                 __builtin_amdgcn_s_barrier();  // slot of step s is filled; slot of step s-1 is drained
                 asm volatile("" ::: "memory");
-                if (s + kRing - 1 < nsteps) stage_next((s + kRing - 1) % kRing);
+                if (s + RING - 1 < nsteps) stage_next((s + RING - 1) % RING);
             }
         };
         if (pw * NWX < W_PIECES) run(std::true_type{});
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
         for (int s = 0; s < nsteps; s++) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const char* ws = lds + (s % kRing) * SLOT;
+            const char* ws = lds + (s % RING) * SLOT;
             const char* ps = ws + W_BYTES;
 #pragma unroll
             for (int kk = 0; kk < RB / 64; kk++) {
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_pc_kernel(const ConvGemmPa
     }
 
     // epilogue: row-wise through LDS when the tensors allow it, lane-wise otherwise
-    constexpr int TPG = conv_stage_tpg(TC, TP, 2, 2, kRing * SLOT);
+    constexpr int TPG = conv_stage_tpg(TC, TP, 2, 2, RING * SLOT);
     static_assert(TPG >= 1, "staging area larger than the ring");
     if (p.row_store_ok) {
         conv_epilogue_lds<T, TC, TP, 2, 2, kThreads, TPG>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
@@ -255,24 +262,24 @@ static long pc_assign_tiles(ConvGemmParams& p, int blk_co, int blk_pix) {
     return total;
 }
 
-template <typename T, int TC, int TP, int RB>
+template <typename T, int TC, int TP, int RB, int RING = kRing>
 static int launch_pc(const ConvGemmParams& p_in, hipStream_t s, char* name, int name_len, const char* tname) {
     ConvGemmParams p = p_in;
-    constexpr size_t kLds = (size_t)kRing * (32 * TC + 32 * TP) * RB;
+    constexpr size_t kLds = (size_t)RING * (32 * TC + 32 * TP) * RB;
     static bool attr_set = false;  // idempotent; a racing second call is harmless
     if (!attr_set) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_pc_kernel<T, TC, TP, RB>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_pc_kernel<T, TC, TP, RB, RING>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_gemm_pc_kernel)");
         if (rc) return rc;
         attr_set = true;
     }
     if (name)
-        snprintf(name, name_len, "void stmi::conv_gemm_pc_kernel<%s, %d, %d, %d>(stmi::ConvGemmParams)", tname, TC, TP, RB);
+        snprintf(name, name_len, "void stmi::conv_gemm_pc_kernel<%s, %d, %d, %d, %d>(stmi::ConvGemmParams)", tname, TC, TP, RB, RING);
     const long tiles = p.nclasses > 0 ? pc_assign_tiles(p, 32 * TC, 32 * TP) : pc_tiles(p, 32 * TC, 32 * TP);
     if (tiles <= 0) return STMI_OK;
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_gemm_pc_kernel<T, TC, TP, RB>), dim3((unsigned)tiles), dim3(kThreads), kLds, s, p);
+    hipLaunchKernelGGL((conv_gemm_pc_kernel<T, TC, TP, RB, RING>), dim3((unsigned)tiles), dim3(kThreads), kLds, s, p);
     STMI_LAUNCH_CHECK("conv_gemm_pc_kernel");
     return STMI_OK;
 }
@@ -290,7 +297,13 @@ static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char*
             return deep ? launch_pc<T, 2, 8, 64>(p, s, name, name_len, tname) : launch_pc<T, 2, 4, 64>(p, s, name, name_len, tname);
         return deep ? launch_pc<T, 1, 8, 64>(p, s, name, name_len, tname) : launch_pc<T, 1, 4, 64>(p, s, name, name_len, tname);
     }
-    if (p.co_pad % 64 != 0) return launch_pc<T, 1, 4, 128>(p, s, name, name_len, tname);
+    // launches of at most eight K steps (the parity classes of the strided layers): a 2-slot ring and twice
+    // the pixels per block.  STMI_PC_WIDE=0 switches that off (tuning aid).
+    static const bool wide = getenv("STMI_PC_WIDE") == nullptr || atoi(getenv("STMI_PC_WIDE")) != 0;
+    const bool shallow = wide && p.ntaps * (p.klen / (128 / (int)sizeof(T))) <= 8;
+    if (p.co_pad % 64 != 0)
+        return shallow ? launch_pc<T, 1, 8, 128, 2>(p, s, name, name_len, tname) : launch_pc<T, 1, 4, 128>(p, s, name, name_len, tname);
+    if (shallow && p.co_pad % 128 != 0) return launch_pc<T, 2, 4, 128, 2>(p, s, name, name_len, tname);
     int cfg = 0;
     if (const char* f = getenv("STMI_PC_CFG")) cfg = atoi(f);
     if (cfg != 1 && cfg != 2) cfg = p.co_pad % 128 == 0 && pc_tiles(p, 128, 64) >= 192 ? 1 : 2;
