@@ -155,16 +155,16 @@ int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean,
                              const float* bias, void* y, void* y_pre, int n, int h, int w, int co, int k, int relu,
                              int dtype, void* stream) {
     if (check_conv("conv2d_rgb_nhwc_fwd", n, h, w, 3, co, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x_f32 && w_packed_rgb && y, "conv2d_rgb_nhwc_fwd: null pointer");
-    if (n == 0) return STMI_OK;
     return conv_rgb_fwd_impl(x_f32, scale, mean, w_packed_rgb, bias, y, y_pre, n, h, w, co, k, relu, dtype, S(stream));
 }
 
 int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, void* dx, int n, int h, int w, int ci,
                                int k, int dtype, void* stream) {
     if (check_conv("conv2d_rgb_nhwc_dgrad", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(dy && w_packed_dgrad_rgb && dx, "conv2d_rgb_nhwc_dgrad: null pointer");
-    if (n == 0) return STMI_OK;
     return conv_rgb_dgrad_impl(dy, w_packed_dgrad_rgb, dx, n, h, w, ci, k, dtype, S(stream));
 }
 
@@ -173,8 +173,8 @@ int stmi_conv2d_to3_supported(int k, int ci, int dtype) { return conv_to3_suppor
 int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const void* addend, void* y, int n, int h,
                              int w, int ci, int k, int dtype, void* stream) {
     if (check_conv("conv2d_to3_nhwc_fwd", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x && w_packed_rowout && y, "conv2d_to3_nhwc_fwd: null pointer");
-    if (n == 0) return STMI_OK;
     return conv_to3_impl(x, w_packed_rowout, addend, y, n, h, w, ci, k, dtype, S(stream));
 }
 

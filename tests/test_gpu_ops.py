@@ -180,6 +180,27 @@ def test_parity_classes_in_one_launch_equal_one_launch_per_class(cuda, dtype, sh
     assert torch.equal(a, b)
 
 
+def test_three_channel_kernels_reject_what_they_are_not_built_for(cuda):
+    """Unsupported geometries fail loudly with the library's message (callers fall back on the row-patch form
+    by asking first); an empty batch is a no-op."""
+    from stmi import ops, lib
+    x = torch.zeros((1, 8, 8, 3), device=cuda)
+    w5 = ops.pack_conv_weights(torch.zeros((5, 5, 3, 32), device=cuda), ops.PACK_FWD_RGB, torch.bfloat16)
+    y = torch.empty((1, 8, 8, 32), device=cuda, dtype=torch.bfloat16)
+    with pytest.raises(lib.StmiError, match='unsupported'):
+        lib.call('stmi_conv2d_rgb_nhwc_fwd', x.data_ptr(), 1.0, None, w5.data_ptr(), None, y.data_ptr(), None,
+                 1, 8, 8, 32, 5, 0, lib.BF16, torch.cuda.current_stream().cuda_stream)
+    assert not ops.to3_supported(5, 32, torch.bfloat16) and not ops.to3_supported(3, 64, torch.float32)
+    assert ops.to3_supported(9, 32, torch.float32) and ops.to3_supported(3, 64, torch.bfloat16)
+    w9 = ops.pack_conv_weights(torch.zeros((9, 9, 3, 32), device=cuda), ops.PACK_FWD_RGB, torch.bfloat16)
+    empty = ops.conv2d_rgb_fwd(torch.zeros((0, 8, 8, 3), device=cuda), w9, 9, 32, torch.bfloat16)
+    assert tuple(empty.shape) == (0, 8, 8, 32)
+    wr = ops.pack_conv_weights(torch.zeros((9, 9, 32, 3), device=cuda), ops.PACK_FWD_ROWOUT, torch.bfloat16)
+    assert tuple(ops.conv2d_to3(torch.zeros((0, 8, 8, 32), device=cuda, dtype=torch.bfloat16), wr, 9).shape) == (0, 8, 8, 3)
+    with pytest.raises(lib.StmiError):   # the pack mode checks its own preconditions
+        ops.pack_conv_weights(torch.zeros((9, 9, 4, 32), device=cuda), ops.PACK_FWD_RGB, torch.bfloat16)
+
+
 TO3_CASES = [(2, 24, 40, 9, 32, False), (1, 37, 45, 9, 32, False), (4, 256, 256, 9, 32, False),
              (2, 16, 60, 3, 64, True), (1, 21, 50, 3, 32, True), (1, 8, 30, 3, 32, False)]
 
