@@ -360,7 +360,14 @@ static bool patch_eligible(const ConvGemmParams& p, int dtype) {
     return true;
 }
 
-static int patch_width(const ConvGemmParams& p) { return p.Wi > 32 ? 64 : (p.Wi > 16 ? 32 : 16); }
+// Patch width: 4 x 32 output pixels on wide images (6 x 34 = 204 halo rows per chunk; the 2 x 64 shape needs
+// 4 x 66 = 264 and measured 1-2 % slower on every layer), the image width class below that.
+// STMI_PATCH_PW=16|32|64 caps it (tuning aid).
+static int patch_width(const ConvGemmParams& p) {
+    static const int cap = getenv("STMI_PATCH_PW") ? atoi(getenv("STMI_PATCH_PW")) : 32;
+    const int w = p.Wi > 32 ? 64 : (p.Wi > 16 ? 32 : 16);
+    return w > cap && (cap == 16 || cap == 32) ? cap : w;
+}
 
 static long patch_tiles(const ConvGemmParams& p, int blk_co) {
     const int pw = patch_width(p), ph = 128 / pw;
