@@ -5,12 +5,15 @@ perceptual + Gram style loss (starry_night weights), synthetic data.
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Started with --gpus N > 1 outside a torchrun environment, it launches the N rank processes itself.
 Prints ONE JSON line on rank 0.  A step = stylizer forward, VGG19 forward on the
 content batch and on the stylized batch, Gram + content + TV losses, the full
 backward, (N > 1: bucketed RCCL gradient all-reduce overlapped with backward),
 TF1 Adam and weight re-packing.  Inputs are resident in HBM before the timed
-region.  Other workloads (--workload infer1080p | gatys) print the same kind of
-line for the other BASELINE.json configurations.
+region.  On one GPU the line also carries "secondary": the other configurations the
+headline metric names (1080p batch-16 inference, Gatys 512x512, fp32 training), each
+with its own roofline object.  --workload infer1080p | gatys runs one of them as the
+headline instead (e.g. under a profiler).
 """
 import argparse
 import json
@@ -47,9 +50,7 @@ def dist_setup(gpus):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if gpus > 1 and world == 1:
-        raise SystemExit('--gpus %d needs one process per GPU: launch with python -m torch.distributed.run '
-                         '--nproc-per-node %d' % (gpus, gpus))
+    assert gpus == 1 or world > 1, 'main() starts the rank processes itself when WORLD_SIZE is unset'
     # Rehearsal on a box with fewer GPUs than ranks: STMI_BENCH_REHEARSE=1 puts every rank on GPU 0 and
     # exchanges over gloo (RCCL wants one device per rank).  Numbers from such a run mean nothing.
     rehearse = os.environ.get('STMI_BENCH_REHEARSE') == '1'
@@ -93,38 +94,44 @@ def timed_steps(step_fn, steps, warmup, world, device):
     return max_over_ranks(time.perf_counter() - t0, world, device)
 
 
-def pmc_entry(kernel_name):
-    """Counter figures of `kernel_name` from the committed counter passes (profiles/r01_pmc_traffic.json,
+def pmc_entry(kernel_name, workload='train'):
+    """Counter figures of `kernel_name` from the committed counter passes (profiles/r*_pmc_traffic*.json,
     written by scripts/make_pmc.sh + scripts/pmc_summary.py: counters cannot be collected from inside this
-    process): HBM-side bytes per launch, MFMA FLOP per launch, MFMA busy fraction; {} when not listed."""
-    import json
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            return json.load(f)['kernels'].get(kernel_name) or {}
-    except (OSError, ValueError, KeyError):
-        return {}
+    process): HBM-side bytes per launch, MFMA FLOP per launch, MFMA busy fraction; {} when not listed.
+    The newest file that lists the kernel for this workload wins."""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    names = sorted(glob.glob(os.path.join(here, 'r*_pmc_traffic_%s.json' % workload)), reverse=True)
+    if workload == 'train':
+        names += sorted(glob.glob(os.path.join(here, 'r*_pmc_traffic.json')), reverse=True)
+    for path in names:
+        try:
+            with open(path) as f:
+                hit = json.load(f)['kernels'].get(kernel_name)
+        except (OSError, ValueError, KeyError):
+            continue
+        if hit:
+            return dict(hit, source=os.path.basename(path))
+    return {}
 
 
-def roofline_train(trainer, dtype_name):
-    """Roofline object of the convolution kernel instantiation with the largest total time.
+def roofline_of(eager_pass, dtype_name, workload):
+    """Roofline object of one workload: the kernel group with the largest total time.
 
-    One eager step logs every stride-1 conv forward / backward-data launch (kernel name as the
-    library reports it, algorithmic flops, a relaunch closure).  The launches of each
-    instantiation are then captured, in step order, into one HIP graph and replayed between two
-    HIP events on the launching stream, so the durations are kernel time (as a profiler's kernel
-    trace shows it), not host launch latency."""
+    `eager_pass()` runs the workload once, un-captured.  While it runs, the library front end logs every
+    stride-1 conv forward / backward-data launch (kernel name as the library reports it, algorithmic
+    flops, a relaunch closure) and every instance-norm call (algorithmic bytes).  The launches of each
+    group are then captured, in step order, into one HIP graph and replayed between two HIP events on
+    the launching stream, so the durations are kernel time (as a profiler's kernel trace shows it),
+    not host launch latency."""
     from stmi import ops
-    trainer_graph = trainer.use_graph
-    trainer.use_graph = False
-    trainer.step()
+    eager_pass()
     torch.cuda.synchronize()
     ops.PROFILE, ops.PROFILE_HBM = [], []
-    trainer.step()
+    eager_pass()
     torch.cuda.synchronize()
     log, ops.PROFILE = ops.PROFILE, None
     hbm_log, ops.PROFILE_HBM = ops.PROFILE_HBM, None
-    trainer.use_graph = trainer_graph
     groups = {}
     for name, flops, relaunch in log:
         groups.setdefault(name, []).append((flops, relaunch))
@@ -152,26 +159,37 @@ def roofline_train(trainer, dtype_name):
         e1.record()
         torch.cuda.synchronize()
         acc[name] = (sum(f for f, _ in calls), e0.elapsed_time(e1) * 1e-3 / reps, len(calls))
+        del graph
     # bandwidth-bound calls: algorithmic bytes / time against the HBM peak
     hbm = {k[4:]: {'achieved': round(v[0] / v[1] / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
                    'frac': round(v[0] / v[1] / 8e12, 4), 'calls_per_step': v[2],
                    'algorithmic_mb_per_step': round(v[0] / 1e6, 1), 'us_per_step': round(v[1] * 1e6, 1)}
            for k, v in acc.items() if k.startswith('hbm:')}
-    acc = {k: v for k, v in acc.items() if not k.startswith('hbm:')}
-    name, (flops, secs, launches) = max(acc.items(), key=lambda kv: kv[1][1])
-    achieved = flops / secs / 1e12
-    pmc = pmc_entry(name)
+    conv = {k: v for k, v in acc.items() if not k.startswith('hbm:')}
+    total = sum(v[1] for v in conv.values())
+    all_conv = {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'launches_per_step': v[2],
+                    'share_of_conv_time': round(v[1] / total, 3)} for k, v in conv.items()}
+    name, (work, secs, launches) = max(acc.items(), key=lambda kv: kv[1][1])
+    if name.startswith('hbm:'):
+        achieved = work / secs / 1e9
+        return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(achieved / 8000.0, 4), 'traffic': pmc_entry(name[4:], workload).get('bytes_per_launch'),
+                'traffic_unit': 'bytes per call', 'kernel': name[4:], 'launches_per_step': launches,
+                'avg_launch_us': round(secs / launches * 1e6, 2),
+                'algorithmic_mb_per_launch': round(work / launches / 1e6, 3),
+                'hbm_bound_calls': hbm, 'all_conv_kernels': all_conv}
+    achieved = work / secs / 1e12
+    pmc = pmc_entry(name, workload)
     peak = PEAK_TFLOPS[dtype_name]
-    total = sum(v[1] for v in acc.values())
     return {
         'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': pmc.get('bytes_per_launch'), 'traffic_unit': 'bytes per launch',
         'mfma_busy_frac_pmc': pmc.get('mfma_busy_frac'), 'mfma_flop_per_launch_pmc': pmc.get('mfma_flop_per_launch'),
+        'pmc_source': pmc.get('source'),
         'kernel': name, 'hbm_bound_calls': hbm,
         'launches_per_step': launches, 'avg_launch_us': round(secs / launches * 1e6, 2),
-        'algorithmic_gflop_per_launch': round(flops / launches / 1e9, 3),
-        'all_conv_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'launches_per_step': v[2],
-                                 'share_of_conv_time': round(v[1] / total, 3)} for k, v in acc.items()},
+        'algorithmic_gflop_per_launch': round(work / launches / 1e9, 3),
+        'all_conv_kernels': all_conv,
     }
 
 
@@ -203,6 +221,116 @@ def cpu_baseline_train(batch_np, style_np, params, vggw, weights, budget_s=25.0)
             'restatement of the reference step; TensorFlow itself is not installable here)' % done}
 
 
+def run_train(args, dtype_name, steps, warmup, world, rank, device, want_roofline, want_cpu):
+    from stmi.stylizer import init_params
+    from stmi.trainer import StyleTrainer
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    rng = np.random.default_rng(1234 + rank)
+    B = args.batch or 4
+    params = init_params(seed=1)
+    vggw = synthetic_vgg()
+    batch = rng.random((B, 256, 256, 3), dtype=np.float32)
+    style = np.random.default_rng(99).random((1, 1014, 1280, 3), dtype=np.float32)
+    tr = StyleTrainer(B, 256, 256, device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype, params=params,
+                      world_size=world, use_graph=not args.no_graph)
+    tr.set_style_image(torch.from_numpy(style))
+    tr.batch_in.copy_(torch.from_numpy(batch))
+    torch.cuda.synchronize()
+    if args.host_input:
+        pinned = torch.from_numpy(batch).pin_memory()
+
+        def step_from_host():
+            tr.batch_in.copy_(pinned, non_blocking=True)
+            tr.step()
+        secs = timed_steps(step_from_host, steps, warmup, world, device)
+    else:
+        secs = timed_steps(lambda: tr.step(), steps, warmup, world, device)
+    losses = tr.read_losses()
+    out = {'metric': 'train img/s (VGG19 Gram loss)', 'unit': 'img/s', 'value': round(B * world * steps / secs, 3),
+           'ms_per_step': round(secs / steps * 1e3, 4), 'scaling': 'weak', 'dtype': dtype_name,
+           'config': {'workload': 'stylizer training step, batch 4x256x256 per GPU, VGG19 perceptual + Gram '
+                      'style loss (starry_night_transfer weights), synthetic COCO-shaped batch',
+                      'global_batch': B * world, 'image': '256x256', 'parallelism': 'dp%d' % world,
+                      'hip_graph': not args.no_graph,
+                      'input': 'pinned host memory, copied every step' if args.host_input else 'resident in HBM'},
+           'final_losses': {'total': float(losses[0]), 'style': float(losses[1]),
+                            'content': float(losses[2]), 'tv': float(losses[3])}}
+    if world > 1 and tr.buckets is not None:
+        out['config']['allreduce'] = tr.comm_report()
+    if rank == 0 and world == 1:
+        if want_roofline:
+            def eager():
+                g, tr.use_graph = tr.use_graph, False
+                tr.step()
+                tr.use_graph = g
+            out['roofline'] = roofline_of(eager, dtype_name, 'train')
+        if want_cpu:
+            out['cpu_baseline'] = cpu_baseline_train(batch, style, params, vggw, STARRY)
+    return out
+
+
+def run_infer(args, dtype_name, steps, warmup, world, rank, device, want_roofline):
+    from stmi.stylizer import StylizerNet, init_params
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    rng = np.random.default_rng(1234 + rank)
+    B = args.batch or 16
+    net = StylizerNet(B, 1080, 1920, device, dtype, params=init_params(seed=1))
+    frames = torch.from_numpy(rng.random((B, 1080, 1920, 3), dtype=np.float32)).to(device)
+    torch.cuda.synchronize()
+    secs = timed_steps(lambda: net.forward(frames), steps, warmup, world, device)
+    out = {'metric': 'stylized img/s @1080p', 'unit': 'img/s', 'value': round(B * world * steps / secs, 3),
+           'ms_per_step': round(secs / steps * 1e3, 4), 'scaling': 'weak', 'dtype': dtype_name, 'steps': steps,
+           'config': {'workload': 'batched 1920x1080 stylizer inference, %d frames per GPU, frames sharded '
+                      'across GPUs with no collective' % B, 'global_batch': B * world,
+                      'input': 'resident in HBM'}}
+    if want_roofline and rank == 0 and world == 1:
+        out['roofline'] = roofline_of(lambda: net.forward(frames), dtype_name, 'infer1080p')
+    return out
+
+
+def run_gatys(args, dtype_name, steps, warmup, world, rank, device, want_roofline):
+    from stmi.trainer import GatysOptimizer
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    rng = np.random.default_rng(1234 + rank)
+    vggw = synthetic_vgg()
+    content = rng.random((1, 512, 512, 3), dtype=np.float32)
+    style = np.random.default_rng(99).random((1, 512, 512, 3), dtype=np.float32)
+    opt = GatysOptimizer(torch.from_numpy(content), device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype,
+                         use_graph=not args.no_graph)
+    opt.set_style_image(torch.from_numpy(style))
+    secs = timed_steps(opt.step, steps, warmup, world, device)
+    out = {'metric': 'Gatys steps/s (512x512, VGG19 Gram + content loss)', 'unit': 'steps/s',
+           'value': round(world * steps / secs, 3), 'ms_per_step': round(secs / steps * 1e3, 4), 'scaling': 'weak',
+           'dtype': dtype_name, 'steps': steps,
+           'config': {'workload': 'Gatys iterative optimisation of one 512x512 image (VGG19 fwd + bwd-data, 5 Gram '
+                      'terms, content and TV terms, TF1 Adam on the image); replicas only'}}
+    if want_roofline and rank == 0 and world == 1:
+        out['roofline'] = roofline_of(opt._run, dtype_name, 'gatys')
+    return out
+
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: start N rank processes (one per GPU) and relay rank 0's
+    line.  This parent never touches the GPU (no HIP call happens before or after the spawn)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    for ln in lines[-1:]:
+        print(ln)
+    other = [ln for ln in proc.stdout.splitlines() if ln not in lines]
+    if other:
+        sys.stderr.write('\n'.join(other) + '\n')
+    raise SystemExit(proc.returncode if proc.returncode or lines else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -213,78 +341,42 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='train, 1 GPU: skip the 1080p-inference, Gatys and fp32-training lines of "secondary"')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--host-input', action='store_true',
                     help='train: copy the batch from pinned host memory inside every timed step (PCIe-inclusive rate)')
     args = ap.parse_args()
 
-    world, rank, device = dist_setup(args.gpus)
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    from stmi.stylizer import StylizerNet, init_params
-    from stmi.trainer import GatysOptimizer, StyleTrainer
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
 
-    rng = np.random.default_rng(1234 + rank)
+    world, rank, device = dist_setup(args.gpus)
     line = {'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True,
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic'}
+    roof = not args.no_roofline
 
     if args.workload == 'train':
-        B = args.batch or 4
-        params = init_params(seed=1)
-        vggw = synthetic_vgg()
-        batch = rng.random((B, 256, 256, 3), dtype=np.float32)
-        style = np.random.default_rng(99).random((1, 1014, 1280, 3), dtype=np.float32)
-        tr = StyleTrainer(B, 256, 256, device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype, params=params,
-                          world_size=world, use_graph=not args.no_graph)
-        tr.set_style_image(torch.from_numpy(style))
-        tr.batch_in.copy_(torch.from_numpy(batch))
-        torch.cuda.synchronize()
-        if args.host_input:
-            pinned = torch.from_numpy(batch).pin_memory()
-
-            def step_from_host():
-                tr.batch_in.copy_(pinned, non_blocking=True)
-                tr.step()
-            secs = timed_steps(step_from_host, args.steps, args.warmup, world, device)
-        else:
-            secs = timed_steps(lambda: tr.step(), args.steps, args.warmup, world, device)
-        losses = tr.read_losses()
-        line.update({'metric': 'train img/s (VGG19 Gram loss)', 'unit': 'img/s',
-                     'value': round(B * world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
-                     'scaling': 'weak',
-                     'config': {'workload': 'stylizer training step, batch 4x256x256 per GPU, VGG19 perceptual + Gram '
-                                'style loss (starry_night_transfer weights), synthetic COCO-shaped batch',
-                                'global_batch': B * world, 'image': '256x256', 'parallelism': 'dp%d' % world,
-                                'hip_graph': not args.no_graph, 'input': 'pinned host memory, copied every step' if args.host_input else 'resident in HBM'},
-                     'final_losses': {'total': float(losses[0]), 'style': float(losses[1]),
-                                      'content': float(losses[2]), 'tv': float(losses[3])}})
-        if rank == 0 and world == 1:
-            if not args.no_roofline:
-                line['roofline'] = roofline_train(tr, args.dtype)
-            if not args.no_cpu_baseline:
-                line['cpu_baseline'] = cpu_baseline_train(batch, style, params, vggw, STARRY)
+        line.update(run_train(args, args.dtype, args.steps, args.warmup, world, rank, device, roof,
+                              not args.no_cpu_baseline))
+        if world == 1 and not args.no_secondary and args.batch is None and not args.host_input:
+            # the other configurations the headline metric names, each with its own roofline; a failure
+            # there is reported in place and never costs the headline line
+            line['secondary'] = []
+            jobs = [('infer1080p', lambda: run_infer(args, 'bf16', 20, 5, world, rank, device, roof)),
+                    ('gatys', lambda: run_gatys(args, 'bf16', 100, 10, world, rank, device, roof)),
+                    ('train_f32', lambda: run_train(args, 'f32', 20, 5, world, rank, device, roof, False))]
+            for name, job in jobs:
+                torch.cuda.empty_cache()
+                try:
+                    line['secondary'].append(dict(job(), name=name))
+                except Exception as exc:  # noqa: BLE001
+                    line['secondary'].append({'name': name, 'error': repr(exc)})
     elif args.workload == 'infer1080p':
-        B = args.batch or 16
-        net = StylizerNet(B, 1080, 1920, device, dtype, params=init_params(seed=1))
-        frames = torch.from_numpy(rng.random((B, 1080, 1920, 3), dtype=np.float32)).to(device)
-        torch.cuda.synchronize()
-        secs = timed_steps(lambda: net.forward(frames), args.steps, args.warmup, world, device)
-        line.update({'metric': 'stylized img/s @1080p', 'unit': 'img/s',
-                     'value': round(B * world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
-                     'scaling': 'weak',
-                     'config': {'workload': 'batched 1920x1080 stylizer inference, %d frames per GPU, frames sharded '
-                                'across GPUs with no collective' % B, 'global_batch': B * world}})
+        line.update(run_infer(args, args.dtype, args.steps, args.warmup, world, rank, device, roof))
     else:
-        vggw = synthetic_vgg()
-        content = rng.random((1, 512, 512, 3), dtype=np.float32)
-        style = np.random.default_rng(99).random((1, 512, 512, 3), dtype=np.float32)
-        opt = GatysOptimizer(torch.from_numpy(content), device, vggw, np.zeros(3, np.float32), *STARRY, dtype=dtype,
-                             use_graph=not args.no_graph)
-        opt.set_style_image(torch.from_numpy(style))
-        secs = timed_steps(opt.step, args.steps, args.warmup, world, device)
-        line.update({'metric': 'Gatys steps/s (512x512, VGG19 Gram + content loss)', 'unit': 'steps/s',
-                     'value': round(world * args.steps / secs, 3), 'ms_per_step': round(secs / args.steps * 1e3, 4),
-                     'scaling': 'weak',
-                     'config': {'workload': 'Gatys iterative optimisation of one 512x512 image; replicas only'}})
+        line.update(run_gatys(args, args.dtype, args.steps, args.warmup, world, rank, device, roof))
+    line['steps'] = args.steps
 
     if rank == 0:
         print(json.dumps(line))

@@ -219,9 +219,11 @@ int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight
 /* ---- optimizer --------------------------------------------------------- */
 /* tf.train.AdamOptimizer update (call sites full_graph_stylizer_network.py:125, :278):
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).
- * step_dev (device int32) is incremented first and gives t; pass NULL to use
- * the host value t instead.  grad_scale multiplies g first (1/world for
- * data-parallel sums). */
+ * step_dev (device int32) gives t; it is incremented first when the host
+ * argument t >= 0 and used as it stands when t < 0 (a further slice of the same
+ * parameter set within one step).  Pass step_dev = NULL to use the host value
+ * t >= 1 instead.  grad_scale multiplies g first (1/world for data-parallel
+ * sums). */
 int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count,
                   float lr, float beta1, float beta2, float eps, float grad_scale,
                   int* step_dev, int t, void* stream);

@@ -1,6 +1,7 @@
 """Per-layer timing of the conv gather-GEMM kernels on the heavy layer shapes of the
 training step (batch 4, 256x256).  STMI_CONV_CFG / STMI_NO_GLDS / STMI_NO_PATCH / STMI_PATCH_CO select the variant."""
 import os, sys
+os.environ.setdefault('STMI_ENV_LIVE', '1')   # this script switches kernel knobs inside one process
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'style-transfer_amd')]

@@ -7,7 +7,8 @@ from test_gpu_step import small_setup, oracle_step
 from stmi import ops
 from stmi.trainer import StyleTrainer
 cuda = torch.device('cuda:0')
-mode = sys.argv[1]  # 'fwd' -> round forward activations; 'bwd' -> round gradients
+mode = sys.argv[1]  # 'fwd' -> round forward activations; 'bwd' -> round gradients;
+# 'fwd_not3' -> forward activations except 3-channel tensors (the stylized image side); 'fwd_only3' -> only those
 
 def rounder(fn, keys):
     def wrapped(*a, **k):
@@ -15,13 +16,15 @@ def rounder(fn, keys):
         outs = r if isinstance(r, tuple) else (r,)
         for o in outs:
             if torch.is_tensor(o) and o.dtype == torch.float32 and o.dim() == 4:
+                if (mode == 'fwd_not3' and o.shape[-1] == 3) or (mode == 'fwd_only3' and o.shape[-1] != 3):
+                    continue
                 o.copy_(o.bfloat16().float())
         return r
     return wrapped
 
-fwd_names = ['conv2d_fwd', 'conv2d_transpose_fwd', 'instance_norm_fwd', 'maxpool_fwd', 'scale_shift']
+fwd_names = ['conv2d_fwd', 'conv2d_to3', 'conv2d_rgb_fwd', 'conv2d_transpose_fwd', 'instance_norm_fwd', 'maxpool_fwd', 'scale_shift']
 bwd_names = ['conv2d_dgrad', 'conv2d_transpose_dgrad', 'instance_norm_bwd', 'maxpool_bwd', 'mse_fwd_bwd', 'tv_loss_fwd_bwd']
-for nm in (fwd_names if mode == 'fwd' else bwd_names):
+for nm in (fwd_names if mode.startswith('fwd') else bwd_names):
     setattr(ops, nm, rounder(getattr(ops, nm), None))
 
 h, w = 64, 48
@@ -36,4 +39,6 @@ cs = []
 for i, (g, r) in enumerate(zip(tr.net.grad_views, ref[0][2])):
     g = g.double().cpu().reshape(-1); r = r.reshape(-1)
     cs.append((g @ r / (g.norm() * r.norm() + 1e-300)).item())
+gf = tr.net.flat_grad.double().cpu(); rf = torch.cat([x.reshape(-1) for x in ref[0][2]])
+print('  flat cos', (gf @ rf / (gf.norm() * rf.norm())).item())
 print('  cos W    ', ' '.join('%.3f' % c for c in cs[0::3]))

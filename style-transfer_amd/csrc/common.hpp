@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
 
 #include "../../include/stmi.h"
 
@@ -147,6 +150,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     __syncthreads();
     return r;
 }
+
+// Tuning knobs are environment variables read ONCE per process (function-local statics are
+// initialised thread-safely): set them before the first launch.  STMI_ENV_LIVE=1 (tuning scripts that
+// switch knobs inside one process) re-reads them on every use instead.
+static inline bool env_live() {
+    static const bool v = getenv("STMI_ENV_LIVE") != nullptr;
+    return v;
+}
+#define STMI_ENV_SET(name) \
+    ([]() -> bool { static const bool v = getenv(name) != nullptr; return ::stmi::env_live() ? getenv(name) != nullptr : v; }())
+#define STMI_ENV_INT(name, dflt)                                                   \
+    ([]() -> int {                                                                 \
+        static const int v = getenv(name) ? atoi(getenv(name)) : (dflt);           \
+        return ::stmi::env_live() ? (getenv(name) ? atoi(getenv(name)) : (dflt)) : v; \
+    }())
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -242,9 +242,8 @@ static bool eligible(const ConvGemmParams& p, int dtype) {
 // Picks the tile: big tiles when they still give every CU two blocks, otherwise smaller
 // ones.  STMI_CONV_CFG=<index> forces a configuration (tuning aid).
 static int pick(const ConvGemmParams& p) {
-    const char* force = getenv("STMI_CONV_CFG");
-    if (force) {
-        const int c = atoi(force);
+    const int c = STMI_ENV_INT("STMI_CONV_CFG", -1);
+    if (c >= 0) {
         if (c >= 0 && c < 5 && p.co_pad % kCfgs[c].blk_co == 0) return c;
     }
     if (p.co_pad % 64 != 0) return 4;
@@ -259,13 +258,13 @@ template <typename T, int TC, int TP, int WC, int WP, int NS>
 static int launch_one(const ConvGemmParams& p, hipStream_t s) {
     constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
     constexpr size_t kLds = (size_t)NS * (BLK_CO + BLK_PIX) * 128;
-    static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; a racing second call is harmless
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
         int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_gemm_glds_kernel)");
         if (rc) return rc;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
@@ -290,13 +289,13 @@ static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
 }
 
 bool try_launch_conv_gemm_glds(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc) {
-    if (!eligible(p, dtype) || getenv("STMI_NO_GLDS")) return false;
+    if (!eligible(p, dtype) || STMI_ENV_SET("STMI_NO_GLDS")) return false;
     *rc = dtype == STMI_BF16 ? launch_typed<bf16_t>(p, s) : launch_typed<float>(p, s);
     return true;
 }
 
 const char* conv_gemm_glds_cfg_name(const ConvGemmParams& p, int dtype) {
-    return eligible(p, dtype) && !getenv("STMI_NO_GLDS") ? kCfgs[pick(p)].name : nullptr;
+    return eligible(p, dtype) && !STMI_ENV_SET("STMI_NO_GLDS") ? kCfgs[pick(p)].name : nullptr;
 }
 
 }  // namespace stmi

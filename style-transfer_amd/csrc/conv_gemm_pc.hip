@@ -266,13 +266,13 @@ template <typename T, int TC, int TP, int RB, int RING = kRing>
 static int launch_pc(const ConvGemmParams& p_in, hipStream_t s, char* name, int name_len, const char* tname) {
     ConvGemmParams p = p_in;
     constexpr size_t kLds = (size_t)RING * (32 * TC + 32 * TP) * RB;
-    static bool attr_set = false;  // idempotent; a racing second call is harmless
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
         int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_pc_kernel<T, TC, TP, RB, RING>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_gemm_pc_kernel)");
         if (rc) return rc;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     if (name)
         snprintf(name, name_len, "void stmi::conv_gemm_pc_kernel<%s, %d, %d, %d, %d>(stmi::ConvGemmParams)", tname, TC, TP, RB, RING);
@@ -299,13 +299,12 @@ static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char*
     }
     // launches of at most eight K steps (the parity classes of the strided layers): a 2-slot ring and twice
     // the pixels per block.  STMI_PC_WIDE=0 switches that off (tuning aid).
-    static const bool wide = getenv("STMI_PC_WIDE") == nullptr || atoi(getenv("STMI_PC_WIDE")) != 0;
+    const bool wide = STMI_ENV_INT("STMI_PC_WIDE", 1) != 0;
     const bool shallow = wide && p.ntaps * (p.klen / (128 / (int)sizeof(T))) <= 8;
     if (p.co_pad % 64 != 0)
         return shallow ? launch_pc<T, 1, 8, 128, 2>(p, s, name, name_len, tname) : launch_pc<T, 1, 4, 128>(p, s, name, name_len, tname);
     if (shallow && p.co_pad % 128 != 0) return launch_pc<T, 2, 4, 128, 2>(p, s, name, name_len, tname);
-    int cfg = 0;
-    if (const char* f = getenv("STMI_PC_CFG")) cfg = atoi(f);
+    int cfg = STMI_ENV_INT("STMI_PC_CFG", 0);
     if (cfg != 1 && cfg != 2) cfg = p.co_pad % 128 == 0 && pc_tiles(p, 128, 64) >= 192 ? 1 : 2;
     if (cfg == 1 && (p.co_pad % 128 != 0 || sizeof(T) == 4)) cfg = 2;  // the fp32 128 x 64 tile spills registers
     if (cfg == 1) return launch_pc<T, 4, 2, 128>(p, s, name, name_len, tname);
@@ -316,7 +315,7 @@ static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char*
 // largest of them, for the tile choice) in one launch.  Needs row-wise stores and one weight set.
 bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     const int rb = pc_row_bytes(p, dtype);
-    if (rb == 0 || p.co_pad % 32 != 0 || getenv("STMI_NO_PC") || getenv("STMI_NO_PC_MULTI")) return false;
+    if (rb == 0 || p.co_pad % 32 != 0 || STMI_ENV_SET("STMI_NO_PC") || STMI_ENV_SET("STMI_NO_PC_MULTI")) return false;
     if ((((uintptr_t)p.in | (uintptr_t)p.wp) & 15) != 0 || p.Ci % (dtype == STMI_BF16 ? 8 : 4) != 0) return false;
     if (!p.row_store_ok || p.w_batch_stride != 0 || p.nclasses < 1 || p.nclasses > 4) return false;
     *rc = dtype == STMI_BF16 ? launch_pc_typed<bf16_t>(p, rb, s, name, name_len, "__bf16")
@@ -326,13 +325,13 @@ bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, 
 
 bool try_launch_conv_gemm_pc(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     const int rb = pc_row_bytes(p, dtype);
-    if (rb == 0 || p.co_pad % 32 != 0 || getenv("STMI_NO_PC")) return false;
+    if (rb == 0 || p.co_pad % 32 != 0 || STMI_ENV_SET("STMI_NO_PC")) return false;
     if ((((uintptr_t)p.in | (uintptr_t)p.wp) & 15) != 0 || p.Ci % (dtype == STMI_BF16 ? 8 : 4) != 0) return false;
     {
         // A launch of fewer than five K steps is all prologue and epilogue: eight producer waves and a 4-deep
         // ring bring nothing there, and the smaller blocks of the same-wave kernel hide more of the latency
         // (Gram backward of the 64..256-channel taps: 60 -> 50 us per step).  STMI_PC_MIN_STEPS: tuning aid.
-        static const int min_steps = getenv("STMI_PC_MIN_STEPS") ? atoi(getenv("STMI_PC_MIN_STEPS")) : 5;
+        const int min_steps = STMI_ENV_INT("STMI_PC_MIN_STEPS", 5);
         if (p.ntaps * (p.klen / (rb / (dtype == STMI_BF16 ? 2 : 4))) < min_steps) return false;
     }
     *rc = dtype == STMI_BF16 ? launch_pc_typed<bf16_t>(p, rb, s, name, name_len, "__bf16")

@@ -364,7 +364,7 @@ static bool patch_eligible(const ConvGemmParams& p, int dtype) {
 // 4 x 66 = 264 and measured 1-2 % slower on every layer), the image width class below that.
 // STMI_PATCH_PW=16|32|64 caps it (tuning aid).
 static int patch_width(const ConvGemmParams& p) {
-    static const int cap = getenv("STMI_PATCH_PW") ? atoi(getenv("STMI_PATCH_PW")) : 32;
+    const int cap = STMI_ENV_INT("STMI_PATCH_PW", 32);
     const int w = p.Wi > 32 ? 64 : (p.Wi > 16 ? 32 : 16);
     return w > cap && (cap == 16 || cap == 32) ? cap : w;
 }
@@ -377,9 +377,8 @@ static long patch_tiles(const ConvGemmParams& p, int blk_co) {
 // The widest channel tile (128, 64, 32) that still spreads the layer over the chip; the narrow
 // ones re-fetch the patch more often.  STMI_PATCH_CO=32|64|128 forces the choice (tuning aid).
 static int patch_blk_co(const ConvGemmParams& p, int dtype) {
-    const char* force = getenv("STMI_PATCH_CO");
-    if (force) {
-        const int c = atoi(force);
+    {
+        const int c = STMI_ENV_INT("STMI_PATCH_CO", 0);
         if ((c == 32 || c == 64 || c == 128) && p.co_pad % c == 0) return c;
     }
     // single-chunk layers are all prologue and epilogue: more, smaller blocks hide more of it
@@ -392,13 +391,13 @@ static int patch_blk_co(const ConvGemmParams& p, int dtype) {
 template <typename T, int TC, int PW, int NSW, bool ONE>
 static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * 4 * kPatchPieces * 8 * 128;
-    static bool attr_set = false;  // idempotent; a racing second call is harmless
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
         int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_kernel<T, TC, PW, NSW, ONE>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_patch_kernel)");
         if (rc) return rc;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     const long tiles = patch_tiles(p, 32 * TC);
     if (tiles <= 0) return STMI_OK;
@@ -432,7 +431,7 @@ static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
 }
 
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
-    if (!patch_eligible(p, dtype) || getenv("STMI_NO_PATCH")) return false;
+    if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
     const int co = patch_blk_co(p, dtype);
     if (name)
         snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",

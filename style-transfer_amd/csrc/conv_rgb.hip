@@ -143,13 +143,13 @@ static int launch_rgb(const XT* x, float scale, const float* mean, const void* w
     constexpr int TPG = conv_stage_tpg(TC, 4, 1, 4, 160 * 1024 / 2);
     constexpr int S_BYTES = 16 * TPG * 4 * (CO + 4) * 4;
     constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_BYTES ? W_BYTES + P_BYTES : S_BYTES) + 15) / 16 * 16;
-    static bool attr_set = false;  // idempotent; a racing second call is harmless
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
         int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC, XT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_rgb_kernel)");
         if (rc) return rc;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     {
         char name[160];

@@ -233,8 +233,8 @@ static int launch_wg(WgradParams& p, hipStream_t s) {
     const long pix_total = batched ? (long)p.Ho * p.Wo : (long)p.N * p.Ho * p.Wo;
     const int rtiles = ceil_div(p.klen, BLK_R), ctiles = ceil_div(p.Co, BLK_C);
     const long tiles = (long)p.ntaps * rtiles * ctiles * (batched ? p.N : 1);
-    const char* tb = getenv("STMI_WG_BLOCKS");
-    const long target = tb ? atol(tb) : (batched ? 512 : 1024);
+    const int tb = STMI_ENV_INT("STMI_WG_BLOCKS", 0);
+    const long target = tb > 0 ? tb : (batched ? 512 : 1024);
     long splits = (target + tiles - 1) / tiles;
     const long max_splits = (pix_total + 4 * BKP - 1) / (4 * BKP);  // at least 4 steps per block
     if (splits > max_splits) splits = max_splits;
@@ -252,8 +252,8 @@ static int launch_wg(WgradParams& p, hipStream_t s) {
 
 template <typename T>
 static int launch_wg_typed(WgradParams& p, hipStream_t s) {
-    if (const char* f = getenv("STMI_WG_CFG")) {
-        switch (atoi(f)) {
+    if (STMI_ENV_SET("STMI_WG_CFG")) {
+        switch (STMI_ENV_INT("STMI_WG_CFG", -1)) {
             case 0: return launch_wg<T, 4, 4, 2, 2>(p, s);
             case 1: return launch_wg<T, 2, 2, 2, 2>(p, s);
             case 2: return launch_wg<T, 2, 1, 4, 1>(p, s);

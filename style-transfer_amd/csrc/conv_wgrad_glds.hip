@@ -297,13 +297,13 @@ template <typename T, int XB, int DB>
 static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
     constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);
     constexpr size_t kLds = (size_t)kRing * kStepPix * (XB + DB);
-    static bool attr_set = false;  // idempotent; a racing second call is harmless
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
         int rc = check_hip(hipFuncSetAttribute((const void*)wgrad_glds_kernel<T, XB, DB>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(wgrad_glds_kernel)");
         if (rc) return rc;
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     WgradParams p = p_in;
     const bool batched = p.batch_out_stride != 0;
@@ -312,8 +312,8 @@ static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
     const long groups = tiles * (batched ? p.N : 1);
     // about one block per CU for 64 x 64 tiles (every extra slice of the pixels costs a tile of
     // atomics), two for the smaller tiles whose atomics are cheap and whose steps are short
-    const char* tb = getenv("STMI_WG_BLOCKS");
-    const long target = tb ? atol(tb) : (TE * TD >= 64 * 64 ? 256 : 512);
+    const int tb = STMI_ENV_INT("STMI_WG_BLOCKS", 0);
+    const long target = tb > 0 ? tb : (TE * TD >= 64 * 64 ? 256 : 512);
     long splits = target / groups;
     const long max_splits = (pix_total + 2 * kStepPix - 1) / (2 * kStepPix);  // at least two steps per block
     if (splits > max_splits) splits = max_splits;
@@ -332,7 +332,7 @@ static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
 }
 
 bool try_launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s, int* rc) {
-    if (!wg_eligible(p, dtype) || getenv("STMI_NO_WG_GLDS")) return false;
+    if (!wg_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_WG_GLDS")) return false;
     const int xb = row_bytes(p.Ci, dtype), db = row_bytes(p.Co, dtype);
     if (dtype != STMI_BF16) *rc = launch_wg_glds<float, 128, 128>(p, s);
     else if (xb == 128) *rc = db == 128 ? launch_wg_glds<bf16_t, 128, 128>(p, s) : launch_wg_glds<bf16_t, 128, 64>(p, s);

@@ -345,7 +345,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 int adam_impl(float* p, const float* g, float* m, float* v, long count, float lr, float b1, float b2, float eps,
               float grad_scale, int* step_dev, int t, hipStream_t s) {
-    if (step_dev) {
+    if (step_dev && t >= 0) {
         hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_dev);
         STMI_LAUNCH_CHECK("bump_step_kernel");
     }

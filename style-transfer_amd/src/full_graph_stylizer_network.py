@@ -304,49 +304,90 @@ def normal_style_transfer(style_type, epochs=None, steps_per_epoch=100, log=prin
 # --------------------------------------------------------------------------
 class StyleNetService(threading.Thread):
     """Thread-backed model holder.  start() loads the weights and flips `loaded`; run_on_image
-    may then be called from any thread (calls are serialised per service: one GPU stream's
-    worth of work each; executors are cached per image size)."""
+    may then be called from any thread.
+
+    Calls on ONE service are serialised by its lock; different services run side by side, each
+    on a HIP stream of its own (the Django view keeps three services and calls them from its
+    request threads, ml_services/style_net_service/views.py:23-30, :52).  Executors (static
+    buffers for one image shape) are cached per shape, least recently used first out, within
+    STMI_SERVICE_CACHE_MB (default 8192) of device memory, so that clients alternating between
+    a few image sizes do not rebuild on every request.
+
+    A failed load is kept in `error`: `loaded` stays False as in the reference, but
+    wait_for_ready() raises instead of polling forever."""
 
     def __init__(self, model_name, model_dir=constants.MODELS_DIR):
         super().__init__()
         self.model_name = model_name
         self.model_dir = model_dir
         self.loaded = False
+        self.error = None
         self._lock = threading.Lock()
-        self._nets = {}
+        self._nets = {}          # (n, h, w) -> executor, in least-recently-used order
         self._params = None
+        self._device = None
+        self._stream = None
+        self._cache_bytes = int(os.environ.get('STMI_SERVICE_CACHE_MB', '8192')) << 20
 
     def run(self):
         print('StyleNetService starting...')
-        model_dir = os.path.join(self.model_dir, self.model_name)
-        if not os.path.isdir(model_dir) and os.path.isdir(self.model_name):
-            model_dir = self.model_name   # the 4-argument CLI form hands over an already joined path
-        path = latest_checkpoint(model_dir)
-        if path is None:
-            raise FileNotFoundError('no saved_*.npz or saved_*.index weight file in ' + model_dir)
-        self._params = load_checkpoint(path)
-        self._device = _device()
+        try:
+            model_dir = os.path.join(self.model_dir, self.model_name)
+            if not os.path.isdir(model_dir) and os.path.isdir(self.model_name):
+                model_dir = self.model_name   # the 4-argument CLI form hands over an already joined path
+            path = latest_checkpoint(model_dir)
+            if path is None:
+                raise FileNotFoundError('no saved_*.npz or saved_*.index weight file in ' + model_dir)
+            self._params = load_checkpoint(path)
+        except BaseException as exc:   # kept for wait_for_ready(); the thread itself has no caller to raise to
+            self.error = exc
+            print('StyleNetService failed to load: %r' % (exc,))
+            return
         print('StyleNetService running.')
         self.loaded = True
 
-    def run_on_image(self, input_image):
+    @staticmethod
+    def _executor_bytes(net):
+        return sum(t.numel() * t.element_size() for t in net._pool) + net.x_in.numel() * net.x_in.element_size() \
+            + net.out_f32.numel() * 4
+
+    def _executor(self, n, h, w):
         from stmi.stylizer import StylizerNet
+        net = self._nets.pop((n, h, w), None)
+        if net is None:
+            net = StylizerNet(n, h, w, self._device, _compute_dtype(), params=self._params)
+            need = self._executor_bytes(net)
+            while self._nets and need + sum(self._executor_bytes(x) for x in self._nets.values()) > self._cache_bytes:
+                self._nets.pop(next(iter(self._nets)))
+        self._nets[(n, h, w)] = net      # most recently used last
+        return net
+
+    def run_on_image(self, input_image):
+        if not self.loaded:
+            raise RuntimeError('StyleNetService %s is not loaded%s' % (
+                self.model_name, '' if self.error is None else ': %r' % (self.error,)))
         x = np.ascontiguousarray(np.asarray(input_image, dtype=np.float32))
         n, h, w, _ = x.shape
         with self._lock:
-            with torch.cuda.device(self._device):
-                net = self._nets.get((n, h, w))
-                if net is None:
-                    net = StylizerNet(n, h, w, self._device, _compute_dtype(), params=self._params)
-                    self._nets = {(n, h, w): net}      # keep one shape resident; 1080p buffers are large
-                out = net.forward(torch.from_numpy(x).to(self._device))
-                return out.cpu().numpy()
+            if self._device is None:
+                self._device = _device()
+                self._stream = torch.cuda.Stream(device=self._device)
+            with torch.cuda.device(self._device), torch.cuda.stream(self._stream):
+                net = self._executor(n, h, w)
+                out = net.forward(torch.from_numpy(x).to(self._device, non_blocking=False))
+                host = out.cpu()        # stream-ordered copy; returns once this service's stream is done
+            return host.numpy()
 
     def close(self):
-        self._nets = {}
+        with self._lock:
+            self._nets = {}
 
     def wait_for_ready(self, increment=.1):
         while not self.loaded:
+            if self.error is not None:
+                raise RuntimeError('StyleNetService %s failed to load' % self.model_name) from self.error
+            if self.ident is not None and not self.is_alive() and not self.loaded:
+                raise RuntimeError('StyleNetService %s stopped without loading a model' % self.model_name)
             time.sleep(increment)
 
 

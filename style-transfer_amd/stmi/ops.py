@@ -436,12 +436,16 @@ def tv_loss_fwd_bwd(img_f32, loss, weight, dtype, out=None):
 
 
 # -------------------------------------------------------------- optimizer
-def adam_tf1(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, step_dev=None, t=0):
+def adam_tf1(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, step_dev=None, t=0, advance=True):
+    """TF1 Adam.  With `step_dev` (int32 [1] on the device) the step number lives on the device, which
+    makes the call replayable inside a HIP graph: advance=True increments it before use; advance=False
+    uses it as it stands (a second slice of the same parameter set in the same step)."""
     for tns, nm in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
         _chk(tns, nm, torch.float32)
         assert tns.numel() == p.numel()
     if step_dev is not None:
         _chk(step_dev, 'step_dev', torch.int32)
+        t = 0 if advance else -1
     _lib.call('stmi_adam_tf1', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr),
               float(beta1), float(beta2), float(eps), float(grad_scale), _ptr(step_dev), int(t), _stream())
 

@@ -31,10 +31,27 @@ def _segments(cuts):
 
 # Block ranges (hi..lo) of the stylizer backward; one all-reduce bucket each, reduced while the next range
 # runs.  Every extra range costs about 47 us per step on one MI355X (a graph boundary, and the weight-gradient
-# branch drained at it), about what the all-reduce of a 3 MB bucket takes: two ranges (3.9 MB behind blocks
-# 15..7, 2.8 MB behind 6..0) overlap the larger bucket for the price of one boundary.  STMI_BWD_CUTS (tuning
-# aid) lists the first block of every range but the last one's: "7" (the default), "11,7", "" (one bucket).
-BWD_SEGMENTS = _segments([c for c in os.environ.get('STMI_BWD_CUTS', '7').split(',') if c.strip()])
+# branch drained at it), so there are two.  The cut sits where the LAST bucket -- the one no backward work is
+# left to hide -- is small: blocks 15..3 own 6.29 MB of the 6.71 MB of gradients and are reduced under the
+# backward of blocks 2..0 (the three full-resolution layers, the longest stretch of the pass per parameter);
+# the 0.40 MB behind blocks 2..0 is exposed, and a collective of that size costs its latency, not bandwidth.
+# Adam then runs per bucket, so the update of the large bucket overlaps the reduction of the small one.
+# This default was chosen on ONE rank (graph-boundary cost measured, all-reduce time estimated); it has not
+# been timed with real peers.  STMI_BWD_CUTS (tuning aid) lists the first block of every range but the last
+# one's: "3" (the default), "7", "11,7", "" (one bucket).
+BWD_SEGMENTS = _segments([c for c in os.environ.get('STMI_BWD_CUTS', '3').split(',') if c.strip()])
+
+
+def _store_targets(owner, grams):
+    """Style targets live in buffers allocated ONCE per executor: a captured step has their
+    addresses baked in, so a later style image must land in the same memory to be seen by
+    replayed graphs."""
+    if owner.style_targets is None:
+        owner.style_targets = [g.clone() for g in grams]
+    else:
+        for t, g in zip(owner.style_targets, grams):
+            assert t.shape == g.shape
+            t.copy_(g)
 
 
 class GradBuckets:
@@ -50,9 +67,11 @@ class GradBuckets:
         assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel()
         for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
             assert a1 == b0, 'gradient buckets must tile the flat buffer'
-        self._pending = []
+        self._pending = {}
+        self.issue_seconds, self.issued = 0.0, 0
 
     def reduce_bucket(self, i):
+        import time
         import torch.distributed as dist
         s, e = self.ranges[i]
         if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -60,12 +79,29 @@ class GradBuckets:
             # HIP-graph launch that is still in flight, that copy was observed never to complete.
             # RCCL reductions are stream-ordered device work and need no such wait.
             torch.cuda.current_stream().synchronize()
-        self._pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        t0 = time.perf_counter()
+        work = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.issue_seconds += time.perf_counter() - t0
+        self.issued += 1
+        self._pending[i] = work
+
+    def wait_bucket(self, i):
+        """Orders the current stream behind bucket i's reduction (RCCL: a stream wait, the host does not block)."""
+        w = self._pending.pop(i, None)
+        if w is not None:
+            w.wait()
 
     def wait(self):
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+        for i in sorted(self._pending):
+            self._pending.pop(i).wait()
+
+    def report(self):
+        """Bucket sizes and the host-side cost of issuing one collective (what sits on the step's critical
+        path between two graph replays)."""
+        mb = [round((e - s) * 4 / 1e6, 3) for s, e in self.ranges]
+        return {'bucket_mb': mb, 'exposed_mb': mb[-1], 'overlapped_mb': round(sum(mb[:-1]), 3),
+                'collectives_issued': self.issued,
+                'host_issue_us_per_collective': round(self.issue_seconds / max(1, self.issued) * 1e6, 1)}
 
 
 class StyleTrainer:
@@ -100,7 +136,7 @@ class StyleTrainer:
         _, h, w, _ = style_f32.shape
         rep = self.vgg.replica(1, h, w, keep_for_backward=False)
         grams, _ = rep.forward(style_f32.to(self.device, torch.float32).contiguous())
-        self.style_targets = [g.clone() for g in grams]
+        _store_targets(self, grams)
         torch.cuda.synchronize()
         return self.style_targets
 
@@ -120,30 +156,56 @@ class StyleTrainer:
                                             self.sw, self.cw, self.tvw, self.losses, content_stream=cs)
         return d_out
 
+    def _adam(self, lo=0, hi=None, advance=True):
+        """TF1 Adam on flat[lo:hi]; `advance` moves the shared step counter (once per step)."""
+        sl = slice(lo, hi)
+        ops.adam_tf1(self.net.flat[sl], self.net.flat_grad[sl], self.m[sl], self.v[sl], self.lr, self.b1, self.b2,
+                     self.eps, grad_scale=1.0 / self.world, step_dev=self.step_dev, advance=advance)
+
     def _update(self):
-        ops.adam_tf1(self.net.flat, self.net.flat_grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
-                     grad_scale=1.0 / self.world, step_dev=self.step_dev)
+        self._adam()
         self.net.repack()
 
     def _segments(self):
-        """The step as a list of callables; an all-reduce bucket becomes ready after each but the last."""
+        """The step as a list of callables.  Data parallel: bucket i is ready after backward range i; the
+        update is one Adam launch per bucket (each waits for its own reduction only) and the re-pack."""
         segs = []
         for si, (hi, lo) in enumerate(BWD_SEGMENTS):
             if si == 0:
                 segs.append(lambda hi=hi, lo=lo: self.net.backward(self._front(), hi, lo))
             else:
                 segs.append(lambda hi=hi, lo=lo: self.net.backward(None, hi, lo))
-        segs.append(self._update)
+        if self.buckets is None:
+            segs.append(self._update)
+            return segs
+        last = len(self.buckets.ranges) - 1
+        for bi, (s, e) in enumerate(self.buckets.ranges):
+            def upd(bi=bi, s=s, e=e):
+                self._adam(s, e, advance=(bi == 0))
+                if bi == last:
+                    self.net.repack()
+            segs.append(upd)
         return segs
+
+    def _between(self, i):
+        """Collective traffic around segment i of a data-parallel step (i counts _segments() entries)."""
+        nb = len(BWD_SEGMENTS)
+        if i < nb:
+            self.buckets.reduce_bucket(i)          # gradients of range i are complete: start reducing them
+
+    def _before(self, i):
+        nb = len(BWD_SEGMENTS)
+        if i >= nb:
+            self.buckets.wait_bucket(i - nb)       # Adam of bucket i - nb needs that bucket only
 
     def _run_eager(self):
         segs = self._segments()
         for i, seg in enumerate(segs):
+            if self.buckets is not None:
+                self._before(i)
             seg()
-            if self.buckets is not None and i < len(BWD_SEGMENTS):
-                self.buckets.reduce_bucket(i)
-            if self.buckets is not None and i == len(BWD_SEGMENTS) - 1:
-                self.buckets.wait()
+            if self.buckets is not None:
+                self._between(i)
 
     def _capture(self):
         # warm-up on a side stream (graph capture needs every lazy initialisation done)
@@ -153,6 +215,13 @@ class StyleTrainer:
             self._run_eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.buckets is not None:
+            # no collective may be in flight on any rank when capture begins
+            import torch.distributed as dist
+            self.buckets.wait()
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            torch.cuda.synchronize()
         segs = self._segments()
         if self.buckets is None:
             g = torch.cuda.CUDAGraph()
@@ -169,6 +238,9 @@ class StyleTrainer:
                     seg()
                 pool = g.pool()
                 self._graphs.append(g)
+
+    def comm_report(self):
+        return None if self.buckets is None else self.buckets.report()
 
     # ----------------------------------------------------------------- step
     def step(self, batch_f32=None):
@@ -189,11 +261,9 @@ class StyleTrainer:
             self._graphs[0].replay()
         else:
             for i, g in enumerate(self._graphs):
+                self._before(i)
                 g.replay()
-                if i < len(BWD_SEGMENTS):
-                    self.buckets.reduce_bucket(i)
-                if i == len(BWD_SEGMENTS) - 1:
-                    self.buckets.wait()
+                self._between(i)
 
     def read_losses(self):
         """[total, style, content, tv] of the last step (synchronises)."""
@@ -233,7 +303,7 @@ class GatysOptimizer:
         _, h, w, _ = style_f32.shape
         rep = self.vgg.replica(1, h, w, keep_for_backward=False)
         grams, _ = rep.forward(style_f32.to(self.device, torch.float32).contiguous())
-        self.style_targets = [g.clone() for g in grams]
+        _store_targets(self, grams)
         torch.cuda.synchronize()
 
     def _run(self):

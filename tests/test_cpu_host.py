@@ -137,15 +137,14 @@ def test_checkpoint_round_trip_and_service_load(tmp_path, monkeypatch):
     (tmp_path / 'STYLE_NET_2019-09-24-20-41').mkdir()
     (tmp_path / 'unrelated').mkdir()
     assert mu.get_most_recent_model_name(str(tmp_path), 'STYLE_NET') == 'STYLE_NET_2019-09-24-20-41'
-    # the service thread loads weights but cannot come up without a GPU: it must fail loudly,
-    # leaving loaded == False (the reference's behaviour for a failed restore)
+    # the service thread only reads the weight file; without a GPU the first run_on_image fails loudly
     if not torch.cuda.is_available():
         svc = fg.StyleNetService('STYLE_NET_2019-09-22-22-24', str(tmp_path))
-        errors = []
-        monkeypatch.setattr(fg.threading, 'excepthook', lambda args: errors.append(args.exc_value))
         svc.start()
         svc.join()
-        assert svc.loaded is False and errors and 'no CPU path' in str(errors[0])
+        assert svc.loaded is True and svc.error is None
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            svc.run_on_image(np.zeros((1, 8, 8, 3), np.float32))
 
 
 def test_image_utilities_round_trip(tmp_path):
@@ -228,3 +227,63 @@ def test_stylizer_executor_layout():
     from stmi.trainer import BWD_SEGMENTS
     covered = [i for hi, lo in BWD_SEGMENTS for i in range(hi, lo - 1, -1)]
     assert covered == list(range(15, -1, -1))
+
+
+# ------------------------------------------------------------------ service error path, Django imports
+def test_service_reports_a_failed_load(tmp_path):
+    import full_graph_stylizer_network as fg
+    svc = fg.StyleNetService('STYLE_NET_missing', str(tmp_path))
+    svc.start()
+    with pytest.raises(RuntimeError, match='failed to load'):
+        svc.wait_for_ready()
+    assert svc.loaded is False and isinstance(svc.error, FileNotFoundError)
+    with pytest.raises(RuntimeError, match='not loaded'):
+        svc.run_on_image(np.zeros((1, 8, 8, 3), np.float32))
+
+
+def test_django_view_imports_resolve_in_the_drop_in():
+    """Everything ml_services/style_net_service/views.py imports from src/ (views.py:15-19) and every
+    helper it calls after `from image_utilities import *` (:48-54) exists in the drop-in directory.
+    When the reference tree is present its view is parsed (as text, never executed) for the list."""
+    import ast
+    import importlib
+    wanted_modules = ['constants', 'full_graph_stylizer_network', 'graph_stylizer_network', 'model_utilities',
+                      'image_utilities']
+    called = ['flip_BR', 'pixel_to_decimal', 'image_3d_to_4d', 'save_image']
+    view = '/root/reference/src/ml_services/style_net_service/views.py'
+    if os.path.exists(view):
+        tree = ast.parse(open(view).read())
+        local = {n.split('.')[0] for n in os.listdir(os.path.join(ROOT, 'style-transfer_amd', 'src'))}
+        mods = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                mods |= {a.name for a in node.names}
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                mods.add(node.module)
+        third_party = {m for m in mods if m.split('.')[0] in ('cv2', 'django', 'sys', 'os', 'numpy')}
+        assert sorted(mods - third_party) == sorted(wanted_modules)
+        assert set(wanted_modules) <= local
+    mods = {m: importlib.import_module(m) for m in wanted_modules}
+    assert mods['graph_stylizer_network'].model_prefix == mods['full_graph_stylizer_network'].model_prefix == 'STYLE_NET'
+    for name in called:
+        assert callable(getattr(mods['image_utilities'], name))
+    svc_cls = mods['full_graph_stylizer_network'].StyleNetService
+    assert mods['graph_stylizer_network'].StyleNetService is svc_cls
+    # constructing and starting services needs no GPU (the view does it at import, views.py:23-30)
+    assert hasattr(mods['constants'], 'MODELS_DIR')
+
+
+def test_service_loads_without_a_gpu_and_says_so_at_first_use(tmp_path):
+    import full_graph_stylizer_network as fg
+    from stmi.stylizer import init_params
+    name = 'STYLE_NET_2019-09-24-15-54'
+    (tmp_path / name).mkdir()
+    fg.save_checkpoint(init_params(seed=1), str(tmp_path / name), name)
+    svc = fg.StyleNetService(name, str(tmp_path))
+    svc.start()
+    svc.wait_for_ready()
+    assert svc.loaded and svc.error is None
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no MI355X visible'):
+            svc.run_on_image(np.zeros((1, 8, 8, 3), np.float32))
+    svc.close()
