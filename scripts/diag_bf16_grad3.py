@@ -42,6 +42,13 @@ def install(names, only3=None):
 
 
 batch, style, params, vggw, mean = small_setup(h=h, w=w)
+if os.environ.get('DIAG_SMOOTH'):
+    # structured pictures instead of white noise: the content difference F - T is then not a small
+    # difference of two near-identical noise responses
+    from test_gpu_e2e import smooth_image
+    rng = np.random.default_rng(5)
+    batch = np.concatenate([smooth_image(rng, h, w) for _ in range(batch.shape[0])]).astype(np.float32)
+    style = smooth_image(rng, style.shape[1], style.shape[2]).astype(np.float32)
 TERMS = {'all': (1e-2, 1e4, 1e8), 'style': (1e-2, 0.0, 0.0), 'content': (0.0, 1e4, 0.0), 'tv': (0.0, 0.0, 1e8)}
 REFS = {}
 for term, (sw, cw, tvw) in TERMS.items():
@@ -49,8 +56,19 @@ for term, (sw, cw, tvw) in TERMS.items():
     REFS[term] = torch.cat([x.reshape(-1) for x in ref[0][2]])
 print('gradient norms per term (oracle):', {k: float(v.norm()) for k, v in REFS.items()})
 
-CASES = [('none', [], None), ('all', ALL, None)] + [(nm, [nm], None) for nm in ALL] + \
-        [('all but 3-channel tensors', ALL, False), ('3-channel tensors only', ALL, True)]
+CASES = [('none', [], None), ('all', ALL, None)]
+if os.environ.get('DIAG_FULL'):
+    CASES += [(nm, [nm], None) for nm in ALL] + [('all but 3-channel tensors', ALL, False),
+                                                 ('3-channel tensors only', ALL, True)]
+# how small is the content difference next to the features themselves (fp64 oracle)?
+from oracle import tf_ops as O
+t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+with torch.no_grad():
+    Wd = {k: (t64(a), t64(b)) for k, (a, b) in vggw.items()}
+    out = O.stylizer_forward(t64(batch), [t64(p) for p in params])
+    _, cf = O.vgg_taps(O.vgg_preprocess(out, t64(mean)), Wd)
+    _, ct = O.vgg_taps(O.vgg_preprocess(t64(batch), t64(mean)), Wd)
+    print('content tap: |F - T| / |F| = %.4f' % ((cf[0] - ct[0]).norm() / cf[0].norm()).item())
 for label, names, only3 in CASES:
     install(names, only3)
     row = []

@@ -151,10 +151,15 @@ def test_training_step_bf16_tracks_oracle(cuda):
     assert psnr(tr.net.out_f32, ref[0][1]) >= 40.0
     for got, want in zip(losses, ref[0][0]):
         assert abs(got - want) <= 5e-2 * abs(want), (losses, ref[0][0])
-    # Gradient direction vs the fp64 oracle.  The deviation is set by bf16 ROUNDING OF THE
-    # FORWARD ACTIVATIONS (the TV term high-passes the output): fp32 kernels fed bf16-rounded
-    # activations give the same ~0.94, while rounding only the backward tensors gives 1.000
-    # (scripts/diag_bf16_grad2.py).  The gate therefore only guards against gross errors.
+    # Gradient direction vs the fp64 oracle.  The deviation comes from ROUNDING THE FORWARD ACTIVATIONS to
+    # bf16, and grows with the depth of the path a loss term's gradient travels: fp32 kernels fed
+    # bf16-rounded activations give per-term cosines TV 0.997, style 0.96, content 0.93 (the content
+    # gradient crosses all fourteen VGG layers and the whole stylizer; ReLU masks and pool routing of a
+    # deep random network shift under 2^-9 perturbations), 0.96 for the sum; rounding only the backward
+    # tensors gives 1.000 (scripts/diag_bf16_grad3.py, scripts/diag_bf16_grad2.py).  The bf16 mode itself
+    # measures 0.94.  It is therefore a reduced-fidelity mode by construction: the gate below guards
+    # against gross errors, fp32 is the parity mode, and the 20-step trajectory test below shows that the
+    # bf16 mode nevertheless drives the loss like fp32.
     g = tr.net.flat_grad.double().cpu()
     r = torch.cat([x.reshape(-1) for x in ref[0][2]])
     cos = (g @ r / (g.norm() * r.norm())).item()
