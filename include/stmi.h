@@ -165,6 +165,17 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
 int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float eps,
                                   int n, int h, int w, int c, int dtype, void* stream);
+/* stmi_instance_norm_nhwc_stats without a workspace argument and without any allocation.  It has no
+ * counterpart in the reference: it exists for callers that cannot allocate device memory (code under
+ * HIP-graph capture, serving loops and harnesses that forbid hipMalloc).  The per-block partial sums
+ * go to a fixed 16 MiB array in device memory that every GPU the process uses holds until the process
+ * ends; n * c must not exceed STMI_IN_STATIC_MAX_NC (otherwise STMI_ERR_INVALID and a message).
+ * Results are bit-identical to stmi_instance_norm_nhwc_stats.  All calls on one GPU share that GPU's
+ * array: calls that overlap in time on the same GPU (different streams or threads) race.  The first
+ * call on a device looks up the array's device address and must happen outside graph capture. */
+#define STMI_IN_STATIC_MAX_NC 8192
+int stmi_instance_norm_nhwc_stats_static(const void* x, float* stats, float eps,
+                                         int n, int h, int w, int c, int dtype, void* stream);
 int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float* scale, const float* shift,
                                   const void* residual, void* y, float* y_f32,
                                   int act, int n, int h, int w, int c,

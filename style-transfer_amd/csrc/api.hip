@@ -43,6 +43,7 @@ int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n
 long in_ws_floats(int n, int h, int w, int c);
 int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
+int in_stats_static_impl(const void* x, float* stats, float eps, int n, int h, int w, int c, int dtype, hipStream_t s);
 int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
                   void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
@@ -225,6 +226,14 @@ int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float 
     STMI_REQUIRE(x && ws && stats && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_stats: bad arguments");
     if (n == 0) return STMI_OK;
     return in_stats_impl(x, ws, stats, eps, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_stats_static(const void* x, float* stats, float eps, int n, int h, int w, int c, int dtype,
+                                         void* stream) {
+    STMI_REQUIRE(x && stats && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_stats_static: bad arguments");
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;
+    return in_stats_static_impl(x, stats, eps, n, h, w, c, dtype, S(stream));
 }
 
 int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float* scale, const float* shift,

@@ -390,6 +390,51 @@ int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int 
                               : stats_typed<float>(x, ws, stats, eps, n, h, w, c, s);
 }
 
+// ---------------------------------------------------------------------------
+// Statistics pass for callers that cannot allocate: the per-block partial sums go to a
+// fixed array in device memory instead of a caller workspace.  Every GPU the process uses
+// holds its own copy of the array for the life of the process; its address on a device is
+// looked up once, with that device current, and kept.
+// ---------------------------------------------------------------------------
+constexpr long kStaticWsFloats = (long)STMI_IN_STATIC_MAX_NC * 2 * kInMaxSplits;   // 16 MiB
+static __device__ __align__(256) float scratch[kStaticWsFloats];
+
+constexpr int kMaxDevices = 64;
+static std::atomic<float*> g_scratch_ptr[kMaxDevices];
+
+int in_stats_static_impl(const void* x, float* stats, float eps, int n, int h, int w, int c, int dtype,
+                         hipStream_t s) {
+    const long need = partial_floats(n, c);
+    if (need > kStaticWsFloats) {
+        set_error("instance_norm_nhwc_stats_static: n * c = %ld exceeds the fixed workspace (n * c <= %ld); "
+                  "use stmi_instance_norm_nhwc_stats with a caller workspace", (long)n * c,
+                  (long)STMI_IN_STATIC_MAX_NC);
+        return STMI_ERR_INVALID;
+    }
+    int dev = -1;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    if (dev < 0 || dev >= kMaxDevices) {
+        set_error("instance_norm_nhwc_stats_static: device ordinal %d out of range", dev);
+        return STMI_ERR_INVALID;
+    }
+    float* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        // host code must never hand the array's NAME to a kernel: the name is a host-side stand-in,
+        // the device address comes from the runtime (and differs per GPU)
+        rc = check_hip(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+        if (rc) return rc;
+        if (!ptr) {
+            set_error("instance_norm_nhwc_stats_static: no device address for the fixed workspace");
+            return STMI_ERR_HIP;
+        }
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    // every partial row the finalize pass reads is written by the partial pass of the same call:
+    // nothing in the array has to start at zero
+    return in_stats_impl(x, ptr, stats, eps, n, h, w, c, dtype, s);
+}
+
 int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
                   void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s) {
     return dtype == STMI_BF16 ? apply_typed<bf16_t>(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, s)

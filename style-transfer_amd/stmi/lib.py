@@ -38,6 +38,7 @@ SIGNATURES = {
     'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_instance_norm_ws_floats': (_c_long, [_c_int] * 4),
     'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
+    'stmi_instance_norm_nhwc_stats_static': (_c_int, [_vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),
