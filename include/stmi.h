@@ -89,6 +89,18 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
 int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
                          int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                          int relu, int dtype, void* stream);
+/* The same convolution (model_utilities.py:236-237) that also leaves per-tile sums of what it wrote, from
+ * which the instance norm that follows it (model_utilities.py:238-239, :282-288) takes its mean and
+ * variance without reading y again.  stmi_conv2d_tile_stats_tiles gives the number of tiles per sample
+ * for a geometry (0: the kernel that runs this geometry emits no statistics; use stmi_conv2d_nhwc_fwd and
+ * stmi_instance_norm_nhwc_stats); tile_stats holds n * 4 * co * tiles floats, laid out
+ * [sample][tile][plane][channel], planes = shift k, sum(y - k), sum((y - k)^2), pixel count.  Consumed by
+ * stmi_instance_norm_nhwc_apply_tiles.  y and y_pre must be 16-byte aligned. */
+int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_nhwc_fwd_tile_stats(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
+                                    float* tile_stats,
+                                    int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                    int relu, int dtype, void* stream);
 
 /* The same convolution for a THREE-channel fp32 image, stride 1 (the stylizer's first layer,
  * full_graph_stylizer_network.py:47; VGG conv1_1, vgg.py:92-96), with the input transformed while it
@@ -165,6 +177,21 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
 int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float eps,
                                   int n, int h, int w, int c, int dtype, void* stream);
+/* stats + apply as one call of two launches: the apply blocks fold the statistics pass's partial sums
+ * themselves (no separate finalize launch); stats[n,c,2] is written as by stmi_instance_norm_nhwc_stats
+ * (same values up to the order of a few fp32 additions). */
+int stmi_instance_norm_nhwc_fwd(const void* x, float* ws, float* stats, float eps,
+                                const float* scale, const float* shift, const void* residual,
+                                void* y, float* y_f32, int act, int n, int h, int w, int c,
+                                int dtype, void* stream);
+/* The same normalisation with the statistics taken from the per-tile sums that
+ * stmi_conv2d_nhwc_fwd_tile_stats left behind while it wrote x: the separate statistics pass over x
+ * (one read of the tensor) is not needed.  `tiles` is the row length stmi_conv2d_tile_stats_tiles
+ * returned.  stats[n,c,2] is WRITTEN (mean, 1/sqrt(var+eps)) for the backward pass. */
+int stmi_instance_norm_nhwc_apply_tiles(const void* x, const float* tile_stats, int tiles, float* stats, float eps,
+                                        const float* scale, const float* shift, const void* residual,
+                                        void* y, float* y_f32, int act, int n, int h, int w, int c,
+                                        int dtype, void* stream);
 /* stmi_instance_norm_nhwc_stats without a workspace argument and without any allocation.  It has no
  * counterpart in the reference: it exists for callers that cannot allocate device memory (code under
  * HIP-graph capture, serving loops and harnesses that forbid hipMalloc).  The per-block partial sums
@@ -204,6 +231,9 @@ int stmi_maxpool2x2_same_bwd(const void* x, const void* dy, void* dx, int n, int
 /* tf.linalg.einsum('bijc,bijd->bcd', F, F) / (H*W)   (model_utilities.py:380-384)
  * f [n,h,w,c] -> g fp32 [n,c,c], overwritten. */
 int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream);
+/* The same, ADDED into g (which the caller cleared, e.g. with stmi_zero_multi): saves the launch that
+ * clears g. */
+int stmi_gram_nhwc_fwd_add(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream);
 /* df[p][c] (+)= sum_d F[p][d] * S[b][c][d], S = (dG + dG^T)/(H*W) in dtype, in the
  * zero-padded K-contiguous layout stmi_gram_mse_fwd_bwd writes
  * (stmi_gram_packed_elems elements).  accumulate != 0 adds into df.  c % 8 == 0. */
@@ -226,6 +256,15 @@ int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* loss,
  * weight * d/d img, overwritten. */
 int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight,
                          int n, int h, int w, int c, int dtype, void* stream);
+
+/* ---- step begin -------------------------------------------------------- */
+/* Clears up to STMI_ZERO_MULTI_MAX fp32 buffers (ptrs[i], counts[i] floats) in ONE launch and, when
+ * step_dev is not NULL, advances that device step counter by one (then stmi_adam_tf1 is called with
+ * t < 0 in the same step).  No reference counterpart: in the reference a session run starts from
+ * fresh gradient accumulators; here the accumulators of a step (losses, flat gradient, Gram matrices)
+ * are caller-owned buffers, and clearing them one launch each would cost more than the work. */
+#define STMI_ZERO_MULTI_MAX 16
+int stmi_zero_multi(float* const* ptrs, const long* counts, int n, int* step_dev, void* stream);
 
 /* ---- optimizer --------------------------------------------------------- */
 /* tf.train.AdamOptimizer update (call sites full_graph_stylizer_network.py:125, :278):

@@ -24,8 +24,13 @@ int check_hip(hipError_t e, const char* what) {
 const char* last_conv_kernel();
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int pack_weights_multi_impl(const float*, void*, const stmi_pack_desc*, int, int, hipStream_t);
+int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats, float eps, const float* scale,
+                        const float* shift, const void* residual, void* y, float* y_f32, int act, int n, int h, int w,
+                        int c, int dtype, hipStream_t s);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
-                  int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s);
+                  int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s,
+                  float* tile_stats = nullptr, int tile_stats_ts = 0);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
@@ -37,12 +42,16 @@ int conv_to3_impl(const void* x, const void* wq, const void* addend, void* y, in
                   int dtype, hipStream_t s);
 int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
                     int stride, int accumulate, int dtype, hipStream_t s);
-int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s);
+int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s, int accumulate);
+int zero_multi_impl(float* const* ptrs, const long* counts, int n, int* step, hipStream_t s);
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
 long in_ws_floats(int n, int h, int w, int c);
 int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
+int in_fwd_impl(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
+                const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype,
+                hipStream_t s);
 int in_stats_static_impl(const void* x, float* stats, float eps, int n, int h, int w, int c, int dtype, hipStream_t s);
 int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
                   void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
@@ -152,6 +161,24 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
     return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream));
 }
 
+int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_fwd_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_nhwc_fwd_tile_stats(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
+                                    float* tile_stats, int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                    int relu, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_fwd_tile_stats", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_fwd && y && tile_stats, "conv2d_nhwc_fwd_tile_stats: null pointer");
+    const int ts = conv_fwd_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+    STMI_REQUIRE(ts > 0, "conv2d_nhwc_fwd_tile_stats: this geometry produces no tile statistics "
+                 "(stmi_conv2d_tile_stats_tiles returned 0)");
+    return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream),
+                         tile_stats, ts);
+}
+
 int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean, const void* w_packed_rgb,
                              const float* bias, void* y, void* y_pre, int n, int h, int w, int co, int k, int relu,
                              int dtype, void* stream) {
@@ -246,6 +273,29 @@ int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float
     return in_apply_impl(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype, S(stream));
 }
 
+int stmi_instance_norm_nhwc_fwd(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
+                                const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c,
+                                int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && ws && stats && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0,
+                 "instance_norm_nhwc_fwd: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_fwd: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_fwd_impl(x, ws, stats, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_apply_tiles(const void* x, const float* tile_stats, int tiles, float* stats, float eps,
+                                        const float* scale, const float* shift, const void* residual, void* y,
+                                        float* y_f32, int act, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && tile_stats && stats && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0 && tiles > 0,
+                 "instance_norm_nhwc_apply_tiles: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_apply_tiles: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_apply_tiles_impl(x, tile_stats, tiles, stats, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype,
+                               S(stream));
+}
+
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats, const float* scale,
                                 const float* shift, void* dx, float* dscale, float* dshift, float* ws, float eps,
                                 int act, int n, int h, int w, int c, int dtype, void* stream) {
@@ -285,7 +335,21 @@ int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int 
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(f && g && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_fwd: bad arguments");
     if (n == 0) return STMI_OK;
-    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream));
+    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream), 0);
+}
+
+int stmi_gram_nhwc_fwd_add(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(f && g && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_fwd_add: bad arguments");
+    if (n == 0) return STMI_OK;
+    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream), 1);
+}
+
+int stmi_zero_multi(float* const* ptrs, const long* counts, int n, int* step_dev, void* stream) {
+    STMI_REQUIRE(n >= 0 && n <= STMI_ZERO_MULTI_MAX && (n == 0 || (ptrs && counts)), "zero_multi: bad arguments (n=%d, at most %d buffers)", n, STMI_ZERO_MULTI_MAX);
+    for (int i = 0; i < n; i++) STMI_REQUIRE(counts[i] == 0 || ptrs[i], "zero_multi: null buffer %d", i);
+    if (n == 0 && !step_dev) return STMI_OK;
+    return zero_multi_impl(ptrs, counts, n, step_dev, S(stream));
 }
 
 int stmi_gram_nhwc_bwd(const void* f, const void* s, void* df, int accumulate, int n, int h, int w, int c, int dtype,

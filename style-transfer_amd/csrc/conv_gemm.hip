@@ -232,6 +232,12 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     const char* tname = dtype == STMI_BF16 ? "__bf16" : "float";
     ConvGemmParams p = p_in;
     set_row_store(p, dtype);
+    if (p.tile_stats) {
+        const int ts = conv_patch_tiles_per_sample(p, dtype);
+        STMI_REQUIRE(ts > 0 && ts == p.tile_stats_ts,
+                     "conv: tile statistics asked for a layer whose kernel does not produce them (tiles %d, caller's %d)",
+                     ts, p.tile_stats_ts);
+    }
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_pc(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_glds(p, dtype, s, &rc)) {
@@ -412,13 +418,24 @@ static void clear_params(ConvGemmParams& p) {
 
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype,
-                  hipStream_t s) {
+                  hipStream_t s, float* tile_stats, int tile_stats_ts) {
     ConvGemmParams p;
     clear_params(p);
     int rc = setup_fwd(p, n, h, w, ci, co, kh, kw, stride);
     if (rc) return rc;
     p.in = x; p.wp = wp; p.out = y; p.out_pre = y_pre; p.bias = bias; p.addend = addend; p.relu = relu;
+    p.tile_stats = tile_stats; p.tile_stats_ts = tile_stats_ts;
     return launch_conv_gemm(p, dtype, s);
+}
+
+// Tiles per sample of the statistics a forward convolution of this geometry can emit (0: it cannot).
+// The answer assumes 16-byte aligned tensors, which is what makes the row-wise epilogue eligible.
+int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    ConvGemmParams p;
+    clear_params(p);
+    if (setup_fwd(p, n, h, w, ci, co, kh, kw, stride)) return 0;
+    p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    return conv_patch_tiles_per_sample(p, dtype);
 }
 
 // Backward-data of conv(n,h,w,ci -> co, k, stride): gathers dy, writes dx.

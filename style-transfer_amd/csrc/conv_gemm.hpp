@@ -33,6 +33,18 @@ struct ConvGemmParams {
     };
     int nclasses;
     SubGrid cls[4];
+    // Per-tile statistics of the written tensor for a following instance norm (LDS-resident patch kernel
+    // only; nullptr = off): tile_stats[sample][tile of the sample][plane][channel], planes = shift k,
+    // sum(x - k), sum((x - k)^2), pixel count; tile_stats_ts = tiles per sample.  One block writes
+    // four contiguous runs of its channels.
+    float* tile_stats;
+    int tile_stats_ts;
+};
+
+// Where one block's statistics go: element (plane, local channel c) is base[plane * C + c].
+struct TileStatsOut {
+    float* base;   // nullptr = no statistics
+    int C, count;
 };
 
 // Epilogue shared by the kernels.  Accumulator tile (tc, tp) of a wave holds, in lane
@@ -147,7 +159,8 @@ constexpr int conv_stage_tpg(int tc, int tp, int wc, int wp, int lds_bytes) {
 
 template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, typename PixelOffset>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
-                                                  float* stage, PixelOffset pixel_offset) {
+                                                  float* stage, PixelOffset pixel_offset,
+                                                  TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0}) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BLK_CO = 16 * TC * WC;
     constexpr int STRIDE = BLK_CO + 4;   // floats; +16 bytes keeps the 16-byte writes conflict-free
@@ -165,6 +178,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
     const T* __restrict__ addend = (const T*)p.addend;
     const int cl_rd = (tid % LPR) * EPC;
     const bool col_ok = co0 + cl_rd < p.Co;
+    const bool want_stats = ts_out.base != nullptr;   // block-uniform
+    float st_k[EPC], st_1[EPC], st_2[EPC];
+#pragma unroll
+    for (int u = 0; u < EPC; u++) st_k[u] = st_1[u] = st_2[u] = 0.f;
 
     f32x4 bias_r[TC];
 #pragma unroll
@@ -192,6 +209,15 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
             }
         }
         __syncthreads();
+        if (want_stats && tp0 == 0) {
+            // shift of the block's sums: the tile's first staged row (in the image or not, it is a
+            // finite value of the right size, and any shift gives the same statistics)
+#pragma unroll
+            for (int u = 0; u < EPC; u += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(stage + cl_rd + u);
+                st_k[u] = t[0]; st_k[u + 1] = t[1]; st_k[u + 2] = t[2]; st_k[u + 3] = t[3];
+            }
+        }
         if (!col_ok) continue;
         for (int rr = tid / LPR; rr < ROWS; rr += RPP) {
             const int w_ = rr / (16 * TPG), rem = rr - w_ * (16 * TPG);
@@ -222,8 +248,51 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
 #pragma unroll
                 for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
             }
+            if (want_stats) {
+#pragma unroll
+                for (int u = 0; u < EPC; u++) {
+                    const float d = v[u] - st_k[u];
+                    st_1[u] += d;
+                    st_2[u] += d * d;
+                }
+            }
             store_vec<T, EPC>(out + e, v);
         }
+    }
+    if (want_stats) {
+        // fold the RPP row owners of every channel: lanes of a wave first, then the waves through LDS
+        static_assert(LPR <= 64 && 64 % LPR == 0, "a wave holds whole pixel rows");
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int u = 0; u < EPC; u++) {
+                st_1[u] += __shfl_xor(st_1[u], o, 64);
+                st_2[u] += __shfl_xor(st_2[u], o, 64);
+            }
+        }
+        constexpr int NW = NT / 64;
+        __syncthreads();  // the last group's rows are consumed
+        if (lane < LPR) {
+#pragma unroll
+            for (int u = 0; u < EPC; u++) {
+                stage[(wave * 2 + 0) * BLK_CO + cl_rd + u] = st_1[u];
+                stage[(wave * 2 + 1) * BLK_CO + cl_rd + u] = st_2[u];
+            }
+        }
+        __syncthreads();
+        if (tid < BLK_CO && co0 + tid < p.Co) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < NW; w_++) {
+                a1 += stage[(w_ * 2 + 0) * BLK_CO + tid];
+                a2 += stage[(w_ * 2 + 1) * BLK_CO + tid];
+            }
+            float* o = ts_out.base + tid;
+            o[ts_out.C] = a1;
+            o[2 * ts_out.C] = a2;
+            o[3 * ts_out.C] = (float)ts_out.count;
+        }
+        if (wave == 1 && lane < LPR && col_ok) store_vec<float, EPC>(ts_out.base + cl_rd, st_k);
     }
 }
 
@@ -270,5 +339,6 @@ bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, 
 // and launches when the problem fits it; name (optional) receives the kernel's name as a
 // profiler prints it.
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
+int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype);
 
 }  // namespace stmi

@@ -329,11 +329,19 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     // epilogue
     const long img = (long)n * H;
     if (p.row_store_ok) {
+        TileStatsOut ts_out{nullptr, 0, 0};
+        if (p.tile_stats) {
+            const int ts = (int)(p.pt_div[1] * p.pt_div[2]);
+            const int tile_in_sample = (ty0 / PH) * (int)p.pt_div[1] + tx0 / PW;
+            ts_out.base = p.tile_stats + (((long)n * ts + tile_in_sample) * 4) * p.Co + co0;
+            ts_out.C = p.Co;
+            ts_out.count = min(PH, H - ty0) * min(PW, W - tx0);
+        }
         conv_epilogue_lds<T, TC, TP, 2, 2, 512, TP>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
             const int f = pl >> 4;
             const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (pl & 15);
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
-        });
+        }, ts_out);
     } else if (wave < 4) {
         const int wc = wave >> 1, wpx = wave & 1;
         const int g = lane >> 4, r16 = lane & 15;
@@ -428,6 +436,14 @@ static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
         case 32: return one ? launch_patch<T, TC, 32, 4, true>(p, s) : launch_patch<T, TC, 32, 4, false>(p, s);
         default: return one ? launch_patch<T, TC, 16, 4, true>(p, s) : launch_patch<T, TC, 16, 4, false>(p, s);
     }
+}
+
+// Tiles per sample the patch kernel would cut this layer into (the number of statistics rows per sample of
+// ConvGemmParams::tile_stats), or 0 when the layer does not run on the patch kernel with row-wise stores.
+int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype) {
+    if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH") || !p.row_store_ok) return 0;
+    const int pw = patch_width(p), ph = 128 / pw;
+    return ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw);
 }
 
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {

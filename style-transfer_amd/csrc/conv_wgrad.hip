@@ -308,7 +308,7 @@ int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int 
 }
 
 // g (fp32, zeroed here) [n,c,c] = F^T F / (h*w)
-int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s) {
+int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s, int accumulate) {
     STMI_REQUIRE(c % 8 == 0, "gram: channel count must be a multiple of 8 (c=%d)", c);
     WgradParams p;
     memset(&p, 0, sizeof(p));
@@ -320,7 +320,7 @@ int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype
     p.ntaps = 1; p.klen = c; p.cdiv = 0;
     p.tap_out_stride = 0;
     p.batch_out_stride = (long)c * c;
-    int rc = zero_f32(g, (long)n * c * c, s);
+    int rc = accumulate ? STMI_OK : zero_f32(g, (long)n * c * c, s);
     if (rc) return rc;
     if (try_launch_wgrad_glds(p, dtype, s, &rc)) return rc;
     if (dtype == STMI_BF16) return launch_wg_typed<bf16_t>(p, s);

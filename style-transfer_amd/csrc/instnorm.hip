@@ -132,22 +132,181 @@ __global__ __launch_bounds__(256) void in_stats_finalize_kernel(const T* __restr
     }
 }
 
-template <typename T, int V>
-__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+// ---------------------------------------------------------------------------
+// Statistics from the per-tile sums a convolution's epilogue leaves behind (conv_gemm.hpp,
+// ConvGemmParams::tile_stats): per sample, plane and channel a row of `ts` tiles holding the tile's
+// shift k, sum(x - k), sum((x - k)^2) and pixel count.  Tiles are combined as groups of samples with
+// their own means (Chan et al.): no cancellation however large the mean is next to the deviation.
+// ---------------------------------------------------------------------------
+struct TileFold {
+    float mean, m2, count;
+};
+
+// tiles[sample][tile][plane][channel]: element (t, plane, c) of sample n
+__device__ __forceinline__ const float* tile_row(const float* tiles, int n, int t, int C, int ts) {
+    return tiles + (((long)n * ts + t) * 4) * C;
+}
+
+// one thread folds all tiles of channel c of sample n (loads are coalesced over the channel threads)
+__device__ __forceinline__ TileFold fold_tiles_serial(const float* __restrict__ tiles, int n, int c, int C, int ts) {
+    const float k0 = tile_row(tiles, n, 0, C, ts)[c];
+    float cnt = 0.f, s = 0.f;
+    for (int t = 0; t < ts; t++) {
+        const float* r = tile_row(tiles, n, t, C, ts);
+        const float ct = r[3 * C + c];
+        cnt += ct;
+        s += ct * (r[c] - k0) + r[C + c];
+    }
+    const float mean = k0 + s / cnt;
+    float m2 = 0.f;
+    for (int t = 0; t < ts; t++) {
+        const float* r = tile_row(tiles, n, t, C, ts);
+        const float ct = r[3 * C + c], s1 = r[C + c], s2 = r[2 * C + c];
+        const float rc = __frcp_rn(ct);
+        const float d = r[c] + s1 * rc - mean;
+        m2 += s2 - s1 * s1 * rc + ct * d * d;
+    }
+    return TileFold{mean, m2, cnt};
+}
+
+// grid (N, ceil(C/16)): 16 channels x 16 tile lanes per block; loads are 64-byte runs of channels
+__global__ __launch_bounds__(256) void in_stats_from_tiles_kernel(const float* __restrict__ tiles,
+                                                                  float* __restrict__ stats, float eps, int C, int ts) {
+    __shared__ float red[3][16][17];
+    const int n = blockIdx.x, cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl;
+    const bool live = c < C;
+    const int cc = live ? c : 0;
+    const float k0 = tile_row(tiles, n, 0, C, ts)[cc];
+    float cnt = 0.f, s = 0.f;
+    for (int t = tl; t < ts; t += 16) {
+        const float* r = tile_row(tiles, n, t, C, ts);
+        const float ct = r[3 * C + cc];
+        cnt += ct;
+        s += ct * (r[cc] - k0) + r[C + cc];
+    }
+    red[0][tl][cl] = cnt;
+    red[1][tl][cl] = s;
+    __syncthreads();
+    cnt = 0.f;
+    s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        cnt += red[0][j][cl];
+        s += red[1][j][cl];
+    }
+    const float mean = k0 + s / cnt;
+    float m2 = 0.f;
+    for (int t = tl; t < ts; t += 16) {
+        const float* r = tile_row(tiles, n, t, C, ts);
+        const float ct = r[3 * C + cc], s1 = r[C + cc], s2 = r[2 * C + cc];
+        const float rc = __frcp_rn(ct);
+        const float d = r[cc] + s1 * rc - mean;
+        m2 += s2 - s1 * s1 * rc + ct * d * d;
+    }
+    red[2][tl][cl] = m2;
+    __syncthreads();
+    if (tl == 0 && live) {
+        m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) m2 += red[2][j][cl];
+        stats[((long)n * C + c) * 2] = mean;
+        stats[((long)n * C + c) * 2 + 1] = 1.f / sqrtf(fmaxf(m2 / cnt, 0.f) + eps);
+    }
+}
+
+// Sums the S partial rows of sample n (2C floats each: [c] first sum, [C + c] second sum) into out[0 .. 2C)
+// in shared memory.  tmp: 256 floats of shared memory.  Every thread of the 256-thread block calls it; the
+// result is visible after the call.  All loads of a thread are independent, so they are in flight together.
+__device__ __forceinline__ void fold_rows_block(const float* __restrict__ rows, int S, int C, float* out, float* tmp) {
+    const int W = 2 * C, tid = threadIdx.x;
+    if (W >= 256) {
+        for (int o = tid; o < W; o += 256) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int s_ = 0; s_ < S; s_++) acc += rows[(long)s_ * W + o];
+            out[o] = acc;
+        }
+        __syncthreads();
+        return;
+    }
+    const int G = 256 / W;  // row groups
+    const int rg = tid / W, o = tid - rg * W;
+    float acc = 0.f;
+    if (rg < G) {
+#pragma unroll 8
+        for (int s_ = rg; s_ < S; s_ += G) acc += rows[(long)s_ * W + o];
+        tmp[rg * W + o] = acc;
+    }
+    __syncthreads();
+    if (tid < W) {
+        float t = 0.f;
+        for (int j = 0; j < G; j++) t += tmp[j * W + tid];
+        out[tid] = t;
+    }
+    __syncthreads();
+}
+
+// SRC: where the per-channel constants come from
+//   0  stats[n][c] = (mean, 1/sqrt(var + eps)), made by an earlier launch
+//   1  the partial rows of in_stats_kernel (ws), folded by every block for itself; block 0 of a sample
+//      leaves (mean, rstd) in `stats` for the backward pass
+//   2  a convolution's tile sums (short rows only), folded the same way
+template <typename T, int V, int SRC>
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, float* __restrict__ stats,
+                                                       const float* __restrict__ src, int ts, float eps,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const T* residual, T* y, float* y_f32, int act, InGeom g) {
+    extern __shared__ float sh[];  // SRC != 0: [2C] a, b  |  [2C] sums  |  [256] scratch
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    if constexpr (SRC == 1) {
+        float* sums = sh + 2 * g.C;
+        fold_rows_block(src + (long)n * g.S * 2 * g.C, g.S, g.C, sums, sums + 2 * g.C);
+        const float inv = 1.f / (float)g.HW;
+        for (int c = tid; c < g.C; c += 256) {
+            const float k = to_f32<T>(x[(long)n * g.HW * g.C + c]);
+            const float m = sums[c] * inv;
+            const float var = fmaxf(sums[g.C + c] * inv - m * m, 0.f);
+            const float mean = k + m, rstd = 1.f / sqrtf(var + eps);
+            const float a = scale[c] * rstd;
+            sh[c] = a;
+            sh[g.C + c] = shift[c] - mean * a;
+            if (blockIdx.x == 0) {
+                stats[((long)n * g.C + c) * 2] = mean;
+                stats[((long)n * g.C + c) * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+    } else if constexpr (SRC == 2) {
+        for (int c = tid; c < g.C; c += 256) {
+            const TileFold f = fold_tiles_serial(src, n, c, g.C, ts);
+            const float rstd = 1.f / sqrtf(fmaxf(f.m2 / f.count, 0.f) + eps);
+            const float a = scale[c] * rstd;
+            sh[c] = a;
+            sh[g.C + c] = shift[c] - f.mean * a;
+            if (blockIdx.x == 0) {
+                stats[((long)n * g.C + c) * 2] = f.mean;
+                stats[((long)n * g.C + c) * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+    }
     if (tid >= slots * CG) return;
     const int slot = tid / CG, cg = tid - slot * CG;
-    const int n = blockIdx.y;
     float a[V], b[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const int c = cg * V + j;
-        const float mean = stats[((long)n * g.C + c) * 2], rstd = stats[((long)n * g.C + c) * 2 + 1];
-        a[j] = scale[c] * rstd;
-        b[j] = shift[c] - mean * a[j];
+        if constexpr (SRC != 0) {
+            a[j] = sh[c];
+            b[j] = sh[g.C + c];
+        } else {
+            const float mean = stats[((long)n * g.C + c) * 2], rstd = stats[((long)n * g.C + c) * 2 + 1];
+            a[j] = scale[c] * rstd;
+            b[j] = shift[c] - mean * a[j];
+        }
     }
     const long sample = (long)n * g.HW * g.C;
     const int stride = gridDim.x * slots;
@@ -232,43 +391,40 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
     block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, g.C, CG, slots, active);
 }
 
-// backward pass 2: means[n][c] = (mean(g), mean(g*xhat)); parameter gradients summed over samples
-__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ means,
-                                                              float* dscale, float* dshift, InGeom g) {
-    const int n = blockIdx.x, c = blockIdx.y * 8 + (threadIdx.x >> 5);
-    float s1, s2;
-    fold_partials(ws, g, n, c, s1, s2);
-    if (c < g.C && (threadIdx.x & 31) == 0) {
-        const float inv = 1.f / (float)g.HW;
-        atomicAdd(dshift + c, s1);
-        atomicAdd(dscale + c, s2);
-        means[((long)n * g.C + c) * 2] = s1 * inv;
-        means[((long)n * g.C + c) * 2 + 1] = s2 * inv;
-    }
-}
-
-// backward pass 3: dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat))
+// backward pass 2 (of two): folds the partial rows of pass 1 itself, then
+// dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat)); block 0 of a sample adds the sample's share of the
+// parameter gradients (summed over samples by atomics, the only ones of the pass)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ means, T* dx, int act, InGeom g) {
+                                                           const float* __restrict__ ws, float* dscale, float* dshift,
+                                                           T* dx, int act, InGeom g) {
+    extern __shared__ float sh[];  // [2C] sums | [256] scratch
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    fold_rows_block(ws + (long)n * g.S * 2 * g.C, g.S, g.C, sh, sh + 2 * g.C);
+    if (blockIdx.x == 0) {
+        for (int c = tid; c < g.C; c += 256) {
+            atomicAdd(dshift + c, sh[c]);
+            atomicAdd(dscale + c, sh[g.C + c]);
+        }
+    }
     if (tid >= slots * CG) return;
     const int slot = tid / CG, cg = tid - slot * CG;
-    const int n = blockIdx.y;
-    float mean[V], rstd[V], sc[V], sh[V], m1[V], m2[V];
+    const float inv = 1.f / (float)g.HW;
+    float mean[V], rstd[V], sc[V], shf[V], m1[V], m2[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const int c = cg * V + j;
         mean[j] = stats[((long)n * g.C + c) * 2];
         rstd[j] = stats[((long)n * g.C + c) * 2 + 1];
-        m1[j] = means[((long)n * g.C + c) * 2];
-        m2[j] = means[((long)n * g.C + c) * 2 + 1];
+        m1[j] = sh[c] * inv;
+        m2[j] = sh[g.C + c] * inv;
         sc[j] = scale[c];
-        sh[j] = shift[c];
+        shf[j] = shift[c];
     }
     const long sample = (long)n * g.HW * g.C;
     const int stride = gridDim.x * slots;
@@ -289,7 +445,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 const float xh = (v[u][j] - mean[j]) * rstd[j];
-                const float gg = d[u][j] * act_grad(sc[j] * xh + sh[j], act);
+                const float gg = d[u][j] * act_grad(sc[j] * xh + shf[j], act);
                 v[u][j] = sc[j] * rstd[j] * (gg - m1[j] - xh * m2[j]);
             }
             store_vec<T, V>(dx + sample + (long)pix * g.C + cg * V, v[u]);
@@ -306,6 +462,13 @@ static int pick_v(int c) {
     return 0;
 }
 
+// Partial rows per sample.  The apply kernels fold the rows themselves (no finalize launch), so a sample has
+// at most kInFoldFloats / 2C of them (32 KiB to fold per apply block), and never more than the plane has
+// rounds of loads for.  The choice depends on the plane and the channel count only, never on the batch size:
+// a sample's result is bit-identical whatever batch it is part of.
+constexpr int kInFoldFloats = 8192;
+constexpr int kInFoldMaxRows = 64;
+
 template <typename T>
 static InGeom make_geom(int n, int h, int w, int c) {
     InGeom g;
@@ -313,16 +476,20 @@ static InGeom make_geom(int n, int h, int w, int c) {
     const int v = pick_v<T>(c) > 0 ? pick_v<T>(c) : 1;
     const int slots = 256 / (c / v);
     long s = ((long)g.HW + slots * kInPpt - 1) / (slots * kInPpt);  // one round of loads per thread
-    if (s > kInMaxSplits) s = kInMaxSplits;
+    long cap = kInFoldFloats / (2L * c);
+    if (cap > kInFoldMaxRows) cap = kInFoldMaxRows;
+    if (cap < 1) cap = 1;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     g.S = (int)s;
     g.chunk = (g.HW + g.S - 1) / g.S;
     return g;
 }
 
+// ~4 pixels per thread on small planes; on large ones few, long blocks (each folds the partial rows first)
 static int apply_blocks(const InGeom& g, int slots) {
-    long b = ((long)g.HW + slots * 4 - 1) / (slots * 4);  // ~4 pixels per thread
-    if (b > 1024) b = 1024;
+    long b = ((long)g.HW + slots * 4 - 1) / (slots * 4);
+    if (b > 128) b = 128;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -335,7 +502,7 @@ static int apply_blocks(const InGeom& g, int slots) {
         else { set_error("instance norm: unsupported channel count %d", c); return STMI_ERR_INVALID; } \
     } while (0)
 
-// workspace layout (floats): [N*S*2C partial sums][N*C*2 backward means]
+// workspace (floats): N*S*2C partial sums; sized for the most rows a sample can have
 static inline long partial_floats(int n, int c) { return (long)n * kInMaxSplits * 2 * c; }
 long in_ws_floats(int n, int h, int w, int c) { return partial_floats(n, c) + (long)n * c * 2; }
 
@@ -352,18 +519,49 @@ static int stats_typed(const void* x, float* ws, float* stats, float eps, int n,
     return STMI_OK;
 }
 
+constexpr int kFoldMaxTiles = 32;  // longer tile rows get a finalize launch instead of a fold in every apply block
+
+static inline size_t fold_shared_bytes(int c) { return (size_t)(4 * c + 256) * sizeof(float); }
+
+// src_kind: 0 statistics already in `stats`; 1 partial rows of the statistics pass in `src`; 2 tile sums in `src`
 template <typename T>
-static int apply_typed(const void* x, const float* stats, const float* scale, const float* shift,
-                       const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c,
-                       hipStream_t s) {
+static int apply_typed(const void* x, float* stats, int src_kind, const float* src, int ts, float eps,
+                       const float* scale, const float* shift, const void* residual, void* y, float* y_f32, int act,
+                       int n, int h, int w, int c, hipStream_t s) {
     const InGeom g = make_geom<T>(n, h, w, c);
+    if (src_kind == 2 && ts > kFoldMaxTiles) {
+        hipLaunchKernelGGL(in_stats_from_tiles_kernel, dim3(n, (c + 15) / 16), dim3(256), 0, s, src, stats, eps, c, ts);
+        src_kind = 0;
+    }
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
-        hipLaunchKernelGGL((in_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x,
-                           stats, scale, shift, (const T*)residual, (T*)y, y_f32, act, g);
+        const dim3 grid(apply_blocks(g, slots), n);
+        if (src_kind == 1)
+            hipLaunchKernelGGL((in_apply_kernel<T, V, 1>), grid, dim3(256), fold_shared_bytes(c), s, (const T*)x, stats,
+                               src, ts, eps, scale, shift, (const T*)residual, (T*)y, y_f32, act, g);
+        else if (src_kind == 2)
+            hipLaunchKernelGGL((in_apply_kernel<T, V, 2>), grid, dim3(256), fold_shared_bytes(c), s, (const T*)x, stats,
+                               src, ts, eps, scale, shift, (const T*)residual, (T*)y, y_f32, act, g);
+        else
+            hipLaunchKernelGGL((in_apply_kernel<T, V, 0>), grid, dim3(256), 0, s, (const T*)x, stats, src, ts, eps,
+                               scale, shift, (const T*)residual, (T*)y, y_f32, act, g);
     });
     STMI_LAUNCH_CHECK("in_apply_kernel");
     return STMI_OK;
+}
+
+// statistics pass + apply in two launches (the apply blocks fold the partial rows themselves)
+template <typename T>
+static int fwd_typed(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
+                     const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c, hipStream_t s) {
+    const InGeom g = make_geom<T>(n, h, w, c);
+    IN_DISPATCH(T, c, {
+        const int slots = 256 / (c / V);
+        hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
+                           (const T*)x, ws, g);
+    });
+    STMI_LAUNCH_CHECK("in_stats_kernel");
+    return apply_typed<T>(x, stats, 1, ws, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
 }
 
 template <typename T>
@@ -371,14 +569,13 @@ static int bwd_typed(const void* x, const void* dy, const float* stats, const fl
                      void* dx, float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c,
                      hipStream_t s) {
     const InGeom g = make_geom<T>(n, h, w, c);
-    float* means = ws + partial_floats(n, c);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, (const T*)dy, stats, scale, shift, ws, act, g);
-        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(n, (c + 7) / 8), dim3(256), 0, s, (const float*)ws, means, dscale, dshift, g);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), 0, s, (const T*)x,
-                           (const T*)dy, stats, scale, shift, (const float*)means, (T*)dx, act, g);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, (const float*)ws, dscale, dshift, (T*)dx,
+                           act, g);
     });
     STMI_LAUNCH_CHECK("in_bwd kernels");
     return STMI_OK;
@@ -437,8 +634,28 @@ int in_stats_static_impl(const void* x, float* stats, float eps, int n, int h, i
 
 int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
                   void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s) {
-    return dtype == STMI_BF16 ? apply_typed<bf16_t>(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, s)
-                              : apply_typed<float>(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
+    float* st = const_cast<float*>(stats);  // read only on this path
+    return dtype == STMI_BF16
+               ? apply_typed<bf16_t>(x, st, 0, nullptr, 0, 0.f, scale, shift, residual, y, y_f32, act, n, h, w, c, s)
+               : apply_typed<float>(x, st, 0, nullptr, 0, 0.f, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
+}
+
+// statistics (written to `stats` for the backward pass) from a convolution's tile sums, then apply
+int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats, float eps, const float* scale,
+                        const float* shift, const void* residual, void* y, float* y_f32, int act, int n, int h, int w,
+                        int c, int dtype, hipStream_t s) {
+    return dtype == STMI_BF16
+               ? apply_typed<bf16_t>(x, stats, 2, tiles, ts, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s)
+               : apply_typed<float>(x, stats, 2, tiles, ts, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
+}
+
+// whole forward: statistics pass, then apply (which also leaves the statistics in `stats`)
+int in_fwd_impl(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
+                const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype,
+                hipStream_t s) {
+    return dtype == STMI_BF16
+               ? fwd_typed<bf16_t>(x, ws, stats, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s)
+               : fwd_typed<float>(x, ws, stats, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
 }
 
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,

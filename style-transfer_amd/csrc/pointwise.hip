@@ -322,6 +322,54 @@ int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int 
     return STMI_OK;
 }
 
+__global__ void bump_step_kernel(int* step);
+
+// ------------------------------------------------------------- step begin
+// Clears several fp32 buffers and advances a step counter in ONE launch: the accumulators of a
+// training step (losses, flat gradient, Gram matrices, row-patch weight gradients) would otherwise
+// each cost a launch of their own.  The table travels by value in the kernel arguments, so a
+// captured graph replays it without a device-side table.
+struct ZeroBatch {
+    float* p[STMI_ZERO_MULTI_MAX];
+    long end[STMI_ZERO_MULTI_MAX];   // running ends of the concatenated ranges, in floats
+    int n;
+    int* step;
+};
+
+__global__ __launch_bounds__(256) void zero_multi_kernel(const ZeroBatch b) {
+    if (b.step && blockIdx.x == 0 && threadIdx.x == 0) b.step[0] += 1;
+    const long total = b.end[b.n - 1];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = 0;
+        while (i >= b.end[k]) k++;
+        b.p[k][i - (k ? b.end[k - 1] : 0)] = 0.f;
+    }
+}
+
+int zero_multi_impl(float* const* ptrs, const long* counts, int n, int* step, hipStream_t s) {
+    ZeroBatch b;
+    memset(&b, 0, sizeof(b));
+    long run = 0;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        if (counts[i] <= 0) continue;
+        run += counts[i];
+        b.p[m] = ptrs[i];
+        b.end[m] = run;
+        m++;
+    }
+    b.n = m;
+    b.step = step;
+    if (m == 0) {
+        if (step) hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step);
+        STMI_LAUNCH_CHECK("bump_step_kernel");
+        return STMI_OK;
+    }
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(flat_blocks(run)), dim3(256), 0, s, b);
+    STMI_LAUNCH_CHECK("zero_multi_kernel");
+    return STMI_OK;
+}
+
 // ----------------------------------------------------------------------- Adam
 __global__ void bump_step_kernel(int* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;

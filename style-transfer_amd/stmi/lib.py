@@ -27,6 +27,8 @@ SIGNATURES = {
     'stmi_pack_conv_weights': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + _CONV + [_c_int, _c_int, _vp]),
+    'stmi_conv2d_tile_stats_tiles': (_c_int, [_c_int] * 9),
+    'stmi_conv2d_nhwc_fwd_tile_stats': (_c_int, [_vp] * 6 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_rgb_nhwc_fwd': (_c_int, [_vp, _c_float] + [_vp] * 5 + [_c_int] * 7 + [_vp]),
     'stmi_conv2d_rgb_nhwc_dgrad': (_c_int, [_vp] * 3 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_to3_supported': (_c_int, [_c_int] * 3),
@@ -40,11 +42,15 @@ SIGNATURES = {
     'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_stats_static': (_c_int, [_vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_fwd': (_c_int, [_vp, _vp, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_apply_tiles': (_c_int, [_vp, _vp, _c_int, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),
     'stmi_maxpool2x2_same_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_maxpool2x2_same_bwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_gram_nhwc_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
+    'stmi_gram_nhwc_fwd_add': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
+    'stmi_zero_multi': (_c_int, [_vp, _vp, _c_int, _vp, _vp]),
     'stmi_gram_packed_elems': (_c_long, [_c_int, _c_int]),
     'stmi_gram_nhwc_bwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_gram_mse_fwd_bwd': (_c_int, [_vp] * 4 + [_c_float, _c_float, _c_int, _c_int, _c_int, _vp]),

@@ -103,8 +103,11 @@ def pack_conv_weights_multi(src_flat, dst_flat, table):
 
 
 # ------------------------------------------------------------------- conv
-def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=False, out=None, out_pre=None):
-    """kshape = (kh, kw, ci, co) of the HWIO weight that was packed with PACK_FWD."""
+def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=False, out=None, out_pre=None,
+               tile_stats=None):
+    """kshape = (kh, kw, ci, co) of the HWIO weight that was packed with PACK_FWD.
+    tile_stats: fp32 [n, conv_tile_stats_tiles(...), 4, co] that receives per-tile sums of the output for
+    instance_norm_fwd(..., tile_stats=)."""
     kh, kw, ci, co = kshape
     n, h, w, c = x.shape
     assert c == ci, (c, ci)
@@ -117,10 +120,26 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
         pre = torch.empty_like(y) if out_pre is None else _chk(out_pre, 'out_pre', x.dtype, oshape)
     if bias is not None:
         _chk(bias, 'bias', torch.float32, (co,))
+    if tile_stats is not None:
+        ts = conv_tile_stats_tiles(x.shape, kshape, stride, x.dtype)
+        _chk(tile_stats, 'tile_stats', torch.float32, (n, ts, 4, co))
+        _conv_call('stmi_conv2d_nhwc_fwd_tile_stats', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                       _ptr(pre), tile_stats.data_ptr(), n, h, w, ci, co, kh, kw, stride,
+                                                       int(relu), _dt(x)),
+                   co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
+        return (y, pre) if want_pre else y
     _conv_call('stmi_conv2d_nhwc_fwd', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
                                         n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x)),
                co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
     return (y, pre) if want_pre else y
+
+
+def conv_tile_stats_tiles(x_shape, kshape, stride, dtype):
+    """Tiles per sample of the statistics conv2d_fwd(..., tile_stats=) emits for this geometry; 0 when the
+    kernel that runs it emits none (then instance_norm_fwd makes its own statistics pass)."""
+    kh, kw, ci, co = kshape
+    n, h, w, _ = x_shape
+    return _lib.load().stmi_conv2d_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, _DT[dtype])
 
 
 RGB_CONFIGS = ((9, 32), (3, 64), (3, 32))  # (k, co) the 3-channel kernel is built for
@@ -297,13 +316,15 @@ def instance_norm_ws(n, h, w, c, device):
 
 
 def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=False, ws=None, out=None, stats=None,
-                      out_f32=None, eps=IN_EPS):
-    """Returns (y, stats[, y_f32]); stats [n,c,2] = (mean, 1/sqrt(var+eps)) for the backward."""
+                      out_f32=None, eps=IN_EPS, tile_stats=None):
+    """Returns (y, stats[, y_f32]); stats [n,c,2] = (mean, 1/sqrt(var+eps)) for the backward.
+    tile_stats: the per-tile sums conv2d_fwd(..., tile_stats=) left while writing x; with them the
+    statistics pass over x is skipped."""
     n, h, w, c = x.shape
     _chk(x, 'x')
     _chk(scale, 'scale', torch.float32, (c,))
     _chk(shift, 'shift', torch.float32, (c,))
-    if ws is None:
+    if ws is None and tile_stats is None:
         ws = instance_norm_ws(n, h, w, c, x.device)
     y = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
     if stats is None:
@@ -313,12 +334,20 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
         y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out_f32 is None else out_f32
     if residual is not None:
         _chk(residual, 'residual', x.dtype, x.shape)
+    if tile_stats is not None:
+        _chk(tile_stats, 'tile_stats', torch.float32)
+        assert tile_stats.dim() == 4 and tuple(tile_stats.shape[2:]) == (4, c) and tile_stats.shape[0] == n, tuple(tile_stats.shape)
+
     def launch():
         s = _stream()
-        _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps),
-                  n, h, w, c, _dt(x), s)
-        _lib.call('stmi_instance_norm_nhwc_apply', x.data_ptr(), stats.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  _ptr(residual), y.data_ptr(), _ptr(y32), act, n, h, w, c, _dt(x), s)
+        if tile_stats is not None:
+            _lib.call('stmi_instance_norm_nhwc_apply_tiles', x.data_ptr(), tile_stats.data_ptr(), tile_stats.shape[1],
+                      stats.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr(), _ptr(residual), y.data_ptr(),
+                      _ptr(y32), act, n, h, w, c, _dt(x), s)
+            return
+        _lib.call('stmi_instance_norm_nhwc_fwd', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps),
+                  scale.data_ptr(), shift.data_ptr(), _ptr(residual), y.data_ptr(), _ptr(y32), act, n, h, w, c,
+                  _dt(x), s)
     launch()
     if PROFILE_HBM is not None:  # one read and one write of the activation (+ the skip tensor, + the fp32 copy)
         nbytes = x.numel() * x.element_size() * (2 + (residual is not None)) + (0 if y32 is None else 4 * x.numel())
@@ -377,12 +406,36 @@ def maxpool_bwd(x, dy, out=None):
 
 
 # ------------------------------------------------------------------- Gram
-def gram_fwd(f, out=None):
+def gram_fwd(f, out=None, accumulate=False):
+    """accumulate: ADD into `out`, which the caller cleared (zero_multi) -- one launch less."""
     n, h, w, c = f.shape
     _chk(f, 'f')
     g = torch.empty((n, c, c), dtype=torch.float32, device=f.device) if out is None else _chk(out, 'out', torch.float32, (n, c, c))
-    _lib.call('stmi_gram_nhwc_fwd', f.data_ptr(), g.data_ptr(), n, h, w, c, _dt(f), _stream())
+    assert out is not None or not accumulate
+    _lib.call('stmi_gram_nhwc_fwd_add' if accumulate else 'stmi_gram_nhwc_fwd', f.data_ptr(), g.data_ptr(), n, h, w, c,
+              _dt(f), _stream())
     return g
+
+
+class ZeroList:
+    """Up to 16 fp32 buffers cleared in one launch (optionally advancing a device step counter);
+    the ctypes tables are built once so that a step only passes pointers."""
+
+    def __init__(self, tensors, step_dev=None):
+        import ctypes
+        tensors = [t for t in tensors if t is not None and t.numel() > 0]
+        assert len(tensors) <= 16
+        for t in tensors:
+            _chk(t, 'buffer', torch.float32)
+        if step_dev is not None:
+            _chk(step_dev, 'step_dev', torch.int32)
+        self._keep = (tensors, step_dev)
+        self._ptrs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self._counts = (ctypes.c_long * len(tensors))(*[t.numel() for t in tensors])
+        self._n = len(tensors)
+
+    def run(self):
+        _lib.call('stmi_zero_multi', self._ptrs, self._counts, self._n, _ptr(self._keep[1]), _stream())
 
 
 def gram_packed_elems(n, c):

@@ -7,6 +7,8 @@ Activations are NHWC in the compute dtype; every buffer is allocated once, so a
 forward/backward pass is a fixed list of kernel launches that can be captured
 in a HIP graph.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -120,6 +122,14 @@ class StylizerNet:
                     b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
                                          device=device)
                     b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
+            # plain convolutions whose kernel can emit per-tile sums of its output: the instance norm
+            # behind them skips its statistics pass.  Off unless STMI_TILE_STATS=1: as measured so far the
+            # epilogue costs the convolution what the statistics pass costs the norm.
+            b.tile_stats = None
+            if kind == 'conv' and b.rows is None and os.environ.get('STMI_TILE_STATS') == '1':
+                ts = ops.conv_tile_stats_tiles((batch, h, w, c), b.kshape, s, dtype)
+                if ts > 0:
+                    b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             b.fwd_mode, b.bwd_mode = fwd_mode, bwd_mode
             b.W, b.shift, b.scale = self.views[3 * i], self.views[3 * i + 1], self.views[3 * i + 2]
             b.pk = pk
@@ -158,9 +168,12 @@ class StylizerNet:
             biggest = max(batch * b.out_h * b.out_w * b.co for b in self.blocks)
             # Gradient buffers: g, the skip gradient, dconv, dx -- and two more, so that a weight
             # gradient still reading an older dconv on the side stream does not hold up the chain.
-            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(6)]
+            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(int(os.environ.get('STMI_GRAD_BUFS', '6')))]
             self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'w' not in _SERIAL else None
-            self._readers = {}  # data_ptr of a gradient buffer -> event after its last side-stream reader
+            self._readers = {}  # data_ptr of a gradient buffer -> (issue number, event) of its last side-stream reader
+            self._reader_seq = 0
+        # the owner clears the row-patch weight-gradient buffers once per step (ops.ZeroList): they are then added to
+        self.dtmp_pre_zeroed = False
         self.repack()
 
     # ------------------------------------------------------------ parameters
@@ -188,6 +201,16 @@ class StylizerNet:
         self._x_f32 = x_f32
         if not self.blocks[0].rgb:
             ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
+        b0 = self.blocks[0]
+        self._rows0_ready = False
+        if self.training and b0.rgb and self._side is not None:
+            # the first layer's weight gradient wants row patches of the input: they depend on nothing the
+            # pass computes, so they are made beside it instead of at the very end of the backward pass
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
+                ops.pixels_to_rows(self.x_in, b0.k, -b0.pad_left, out=b0.rows_buf)
+            self._rows0_ready = True
         cur = self.x_in
         skip = None
         last = len(self.blocks) - 1
@@ -212,12 +235,12 @@ class StylizerNet:
                 ops.conv2d_fwd(cur, b.wp_fwd, (b.k, 1, b.ci, 32), 1, out=b.rows_buf)
                 ops.rows_to_pixels_sum(b.rows_buf, b.co, b.k, -b.pad_left, out=conv_out)
             else:
-                ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+                ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             if b.role == 'a':
                 skip = cur
             ops.instance_norm_fwd(conv_out, b.scale, b.shift, b.act, residual=skip if b.role == 'b' else None,
                                   want_f32=(i == last), ws=self.ws, out=y, stats=b.stats,
-                                  out_f32=self.out_f32 if i == last else None)
+                                  out_f32=self.out_f32 if i == last else None, tile_stats=b.tile_stats)
             if b.role == 'b':
                 skip = None
             cur = y
@@ -244,13 +267,16 @@ class StylizerNet:
         main, side = torch.cuda.current_stream(), self._side
 
         def writable(exclude):
-            """Two buffers to overwrite: ones no weight-gradient kernel is still reading come first."""
+            """Two buffers to overwrite.  Buffers no weight-gradient kernel has read come first, then those
+            whose reader was issued LONGEST ago: in a captured graph every wait is a dependency edge, whether
+            or not the reader would long be done at run time, and an edge to the weight gradient that has
+            only just been issued stalls the chain for that kernel's whole duration."""
             free = [p for p in bufs if p.data_ptr() not in exclude]
-            free.sort(key=lambda p: p.data_ptr() in self._readers)
+            free.sort(key=lambda p: self._readers.get(p.data_ptr(), (-1, None))[0])
             for p in free[:2]:
-                ev = self._readers.pop(p.data_ptr(), None)
-                if ev is not None:
-                    main.wait_event(ev)
+                seq_ev = self._readers.pop(p.data_ptr(), None)
+                if seq_ev is not None:
+                    main.wait_event(seq_ev[1])
             return free[0], free[1]
 
         def fork():
@@ -274,7 +300,8 @@ class StylizerNet:
                 fn()
                 ev = torch.cuda.Event()
                 ev.record(side)
-            self._readers[buf.data_ptr()] = ev
+            self._reader_seq += 1
+            self._readers[buf.data_ptr()] = (self._reader_seq, ev)
 
         for i in range(hi, lo - 1, -1):
             b = self.blocks[i]
@@ -290,22 +317,22 @@ class StylizerNet:
                 wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
             elif b.rows == 'in':      # rows_buf still holds the forward's input patches, unless the forward
                 def wgrad():          # ran the 3-channel kernel: then they are made here, beside the chain
-                    if b.rgb:
+                    if b.rgb and not self._rows0_ready:
                         x32 = self._x_f32
                         ops.cast(x32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x32)
                         ops.pixels_to_rows(self.x_in, b.k, -b.pad_left, out=b.rows_buf)
-                    ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp)
+                    ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
             elif b.rows == 'out' and b.rgb_bwd:   # row patches of dconv: for the weight gradient only
                 def wgrad():
                     rg = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
-                    ops.conv2d_wgrad(x_in, rg, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
+                    ops.conv2d_wgrad(x_in, rg, (b.k, 1, b.ci, 32), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             elif b.rows == 'out':
                 rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
 
                 def wgrad():
-                    ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp)
+                    ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             else:
                 wgrad = lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)

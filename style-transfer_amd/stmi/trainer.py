@@ -127,6 +127,12 @@ class StyleTrainer:
             self.buckets = GradBuckets(self.net.flat_grad, [self.net.param_range(hi, lo) for hi, lo in BWD_SEGMENTS],
                                        group)
         self._graphs = None
+        # every accumulator of a step cleared by ONE launch, which also advances the Adam step counter
+        dtmps = [b.dtmp for b in self.net.blocks if b.rows]
+        self._zero = ops.ZeroList([self.losses, self.net.flat_grad] + list(self.rep_loss.grams) + dtmps,
+                                  step_dev=self.step_dev)
+        self.rep_loss.grams_pre_zeroed = True
+        self.net.dtmp_pre_zeroed = True
         # the content targets only meet the rest of the step at the content loss
         self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'c' not in _SERIAL else None
 
@@ -142,8 +148,7 @@ class StyleTrainer:
 
     # --------------------------------------------------------------- pieces
     def _front(self):
-        self.losses.zero_()
-        self.net.flat_grad.zero_()
+        self._zero.run()
         cs = self._content_stream
         if cs is not None:
             cs.wait_stream(torch.cuda.current_stream())
@@ -157,10 +162,10 @@ class StyleTrainer:
         return d_out
 
     def _adam(self, lo=0, hi=None, advance=True):
-        """TF1 Adam on flat[lo:hi]; `advance` moves the shared step counter (once per step)."""
+        """TF1 Adam on flat[lo:hi]; the step counter was advanced by the launch that cleared the accumulators."""
         sl = slice(lo, hi)
         ops.adam_tf1(self.net.flat[sl], self.net.flat_grad[sl], self.m[sl], self.v[sl], self.lr, self.b1, self.b2,
-                     self.eps, grad_scale=1.0 / self.world, step_dev=self.step_dev, advance=advance)
+                     self.eps, grad_scale=1.0 / self.world, step_dev=self.step_dev, advance=False)
 
     def _update(self):
         self._adam()
@@ -297,6 +302,8 @@ class GatysOptimizer:
         self.v = torch.zeros_like(self.image)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.losses = torch.zeros(4, dtype=torch.float32, device=device)
+        self._zero = ops.ZeroList([self.losses] + list(self.rep.grams), step_dev=self.step_dev)
+        self.rep.grams_pre_zeroed = True
         self._graph = None
 
     def set_style_image(self, style_f32):
@@ -307,14 +314,15 @@ class GatysOptimizer:
         torch.cuda.synchronize()
 
     def _run(self):
-        self.losses.zero_()
+        self._zero.run()
         d = self.rep.loss_and_grad(self.image, self.style_targets, self.content_target, self.sw, self.cw, self.tvw,
                                    self.losses)
         if self.dtype == torch.float32:
             g = d
         else:
             g = ops.cast(d, torch.float32, out=self.grad32)
-        ops.adam_tf1(self.image, g, self.m, self.v, self.lr, self.b1, self.b2, self.eps, step_dev=self.step_dev)
+        ops.adam_tf1(self.image, g, self.m, self.v, self.lr, self.b1, self.b2, self.eps, step_dev=self.step_dev,
+                     advance=False)
         # the reference's clip (:328-329) only builds an un-run assign op: the image is NOT clipped
 
     def step(self):

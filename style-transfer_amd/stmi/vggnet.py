@@ -130,6 +130,8 @@ class VggReplica:
         self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
         self._style_job = None
         self._deferred = []  # (event at the fork point, job) not yet issued on the side stream
+        self._style_done = {}  # style layer index (or 'tv') -> event on the side stream after its loss term and gradient
+        self.grams_pre_zeroed = False  # the owner clears self.grams once per step (ops.ZeroList): gram_fwd then only adds
 
     def _buf(self, pool, shape, avoid):
         n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -217,9 +219,13 @@ class VggReplica:
         self._deferred.clear()
 
     def _gram_job(self, li, tensor):
-        ops.gram_fwd(tensor, out=self.grams[li])
+        ops.gram_fwd(tensor, out=self.grams[li], accumulate=self.grams_pre_zeroed)
         if self._style_job is not None:
             self._style_job(li, tensor)
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._style_done[li] = ev
 
     def _tap(self, name, tensor):
         if tensor is None:
@@ -261,7 +267,20 @@ class VggReplica:
             ops.gram_bwd(tap, self.s_packed[li], self.gram_grad[li], accumulate=False)
 
         # the TV term needs only the image and its gradient joins at the very end: beside the chain
-        tv = lambda: ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+        def tv():
+            ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._style_done['tv'] = ev
+
+        def join(key):
+            """The backward chain meets a side-stream result where it first needs it, not before."""
+            ev = self._style_done.pop(key, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+        self._style_done.clear()
         if self._side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -272,8 +291,6 @@ class VggReplica:
         self._style_job = None
         if content_stream is not None:
             torch.cuda.current_stream().wait_stream(content_stream)
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
         cnt = self.content.numel()
         ops.mse_fwd_bwd(self.content, content_target, l_content, content_weight / cnt, 2.0 * content_weight / cnt,
                         out=self.d_content)
@@ -288,6 +305,7 @@ class VggReplica:
             if name.startswith('conv'):
                 if name in self.style_names and name not in joined:
                     # no masked data-gradient kernel produced g (the tap feeds a pool): add it here
+                    join(self.style_names.index(name))
                     ops.gram_bwd(self.pre[name], self.s_packed[self.style_names.index(name)], g, accumulate=True)
                 L = net.convs[name]
                 in_name = names[idx - 1] if idx > 0 else None
@@ -295,6 +313,7 @@ class VggReplica:
                 if in_name is None and L.rows:
                     # d(preprocess)/dx = 255/2 is in the weights; the TV gradient joins in the row sum
                     k, ci = L.kshape[0], L.kshape[2]
+                    join('tv')
                     if ci == 3 and ops.to3_supported(k, L.kshape[3], net.dtype) and 'r' not in _SERIAL:
                         ops.conv2d_to3(g, L.wp_bwd_rows, k, addend=self.tv_grad, out=self.d_image)
                     else:
@@ -304,6 +323,7 @@ class VggReplica:
                     g = self.d_image
                 elif in_name is None:
                     # d(preprocess)/dx = 255/2; the TV gradient joins here
+                    join('tv')
                     ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), alpha=255.0 / 2.0, addend=self.tv_grad,
                                      out=self.d_image)
                     g = self.d_image
@@ -312,6 +332,7 @@ class VggReplica:
                     below = names[idx - 2]  # the conv under that ReLU: its Gram gradient joins after the mask
                     addend = None
                     if below in self.style_names and below in self.pre:
+                        join(self.style_names.index(below))
                         addend = self.gram_grad[self.style_names.index(below)]
                         joined.add(below)
                     ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=self.act[in_name], addend=addend,
@@ -327,4 +348,7 @@ class VggReplica:
                     g = dx
                     idx -= 2
             idx -= 1
+        if self._side is not None:   # whatever the chain did not meet on its way (nothing, on the training path)
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._style_done.clear()
         return self.d_image

@@ -276,7 +276,10 @@ def test_gatys_steps_bf16(cuda):
         print('Gatys 30 steps %s: total loss %.1f (fp32 %.1f), PSNR vs fp32 picture %.2f dB'
               % (key, final[key][0], f32[0], psnr(final[key][1], f32[1])))
         assert abs(final[key][0] - f32[0]) <= 0.1 * f32[0], (final[key][0], f32[0])
-    assert torch.equal(final[(torch.bfloat16, False)][1], final[(torch.bfloat16, True)][1]), 'graph replay == eager'
+    # graph replay against eager launches: the same kernels in the same order; the Gram matrices are summed
+    # by float atomics whose order is free, so the pictures agree closely, not bit for bit
+    assert psnr(final[(torch.bfloat16, False)][1], final[(torch.bfloat16, True)][1]) >= 45.0
+    assert abs(final[(torch.bfloat16, False)][0] - final[(torch.bfloat16, True)][0]) <= 1e-3 * f32[0]
 
 
 def test_style_swap_after_graph_capture(cuda):

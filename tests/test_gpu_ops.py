@@ -293,6 +293,53 @@ def test_instance_norm_fwd_bwd(cuda, dtype, case):
     assert rel_err(dshift, gh) <= 1e-3
 
 
+TILE_STAT_CASES = [
+    # n, h, w, ci, co: 3x3 stride-1 layers of the LDS-resident patch kernel; ragged tiles in both directions,
+    # one tile per sample, many tiles (a finalize launch instead of the fold inside the apply blocks)
+    (2, 16, 32, 128, 128), (1, 5, 70, 64, 64), (2, 11, 40, 128, 64), (1, 3, 2, 64, 64), (3, 64, 64, 128, 128),
+    (1, 70, 150, 64, 128),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', TILE_STAT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_tile_statistics_feed_instance_norm(cuda, dtype, case):
+    """conv2d_fwd(tile_stats=) + instance_norm_fwd(tile_stats=) against conv -> statistics pass -> apply, and
+    against the oracle.  A large mean next to the deviation exercises the shifted tile sums."""
+    from stmi import ops
+    n, h, w, ci, co = case
+    x = rnd((n, h, w, ci), 1)
+    wgt = rnd((3, 3, ci, co), 2, 0.05)
+    wgt[1, 1] += 0.2          # strong centre tap on a non-zero-mean input: |mean| of the output >> its deviation
+    x = x * 0.3 + 1.0
+    scale, shift = rnd((co,), 3) + 1.5, rnd((co,), 4)
+    xd = x.to(cuda, dtype)
+    wp = ops.pack_conv_weights(wgt.to(cuda, torch.float32).contiguous(), ops.PACK_FWD, dtype)
+    ts = ops.conv_tile_stats_tiles(xd.shape, (3, 3, ci, co), 1, dtype)
+    assert ts > 0, 'this geometry runs on the patch kernel'
+    tiles = torch.full((n, ts, 4, co), float('nan'), dtype=torch.float32, device=cuda)
+    y_conv = ops.conv2d_fwd(xd, wp, (3, 3, ci, co), 1, tile_stats=tiles)
+    assert torch.equal(y_conv, ops.conv2d_fwd(xd, wp, (3, 3, ci, co), 1)), 'the statistics must not change the output'
+    assert bool(torch.isfinite(tiles).all())
+    assert tiles[:, :, 3].sum(dim=1).eq(h * w).all(), 'tile pixel counts add up to the plane'
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    y_a, st_a = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU, tile_stats=tiles)
+    y_b, st_b = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU)
+    # The tile path takes the statistics of the fp32 accumulators, the separate pass those of the stored
+    # (rounded) tensor: the first is held to the oracle tightly, the second as far as bf16 storage allows
+    # (with |mean| >> deviation and few pixels the rounding of the stored values shows in the variance).
+    conv_ref = O.conv2d_same(q(x, dtype), q(wgt, dtype), 1)
+    mean_ref = conv_ref.mean(dim=(1, 2))
+    rstd_ref = 1.0 / torch.sqrt(conv_ref.var(dim=(1, 2), unbiased=False) + 1e-3)
+    assert rel_err(st_a[..., 0], mean_ref) <= 1e-4
+    assert rel_err(st_a[..., 1], rstd_ref) <= 1e-3
+    assert rel_err(st_b[..., 0], mean_ref) <= (1e-4 if dtype == torch.float32 else 2e-3)
+    assert rel_err(st_b[..., 1], rstd_ref) <= (1e-3 if dtype == torch.float32 else 5e-2)
+    ref = torch.relu(O.instance_norm(conv_ref, scale.float().double(), shift.float().double()))
+    assert rel_err(y_a, ref) <= TOL[dtype]
+    assert rel_err(y_b, ref) <= TOL[dtype]
+
+
 def test_instance_norm_workspace_is_reusable(cuda):
     """One workspace serves calls of different shapes in a row, and a repeated call gives the same bits."""
     from stmi import ops
