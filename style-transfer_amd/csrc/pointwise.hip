@@ -232,23 +232,38 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
     t -= b * tiles_r * tiles_c;
     const int row0 = (t / tiles_c) * TS, col0 = (t % tiles_c) * TS;
     const float* gb = g + (long)b * c * c;
+    // Each thread owns TS*TS/256 elements of the tile; all their loads are issued before the first use
+    // (the tile is a few KB: the kernel is one memory round trip long, not one per element).
+    constexpr int PER = TS * TS / 256;
+    float dm[PER], dd[PER];
     // mirrored tile: element (col0 + i, row0 + j), read along j
-    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = threadIdx.x + u * 256;
         const int i = e / TS, j = e - i * TS;
         const int r = col0 + i, q = row0 + j;
-        mir[i][j] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
+        dm[u] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
+        const int row = row0 + i, col = col0 + j;
+        dd[u] = row < c && col < c ? gb[row * c + col] - target[row * c + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = threadIdx.x + u * 256;
+        const int i = e / TS, j = e - i * TS;
+        mir[i][j] = dm[u];
     }
     __syncthreads();
     float acc = 0.f;
-    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = threadIdx.x + u * 256;
         const int i = e / TS, j = e - i * TS;
         const int row = row0 + i, col = col0 + j;
         if (row >= rows_pad) continue;
         float v = 0.f;
         if (row < c && col < c) {
-            const float d = gb[row * c + col] - target[row * c + col];
-            acc += d * d;
-            v = grad_scale * 0.5f * (d + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
+            acc += dd[u] * dd[u];
+            v = grad_scale * 0.5f * (dd[u] + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
         }
         sout[((long)b * rows_pad + row) * kpad + col] = from_f32<T>(v);
     }

@@ -128,6 +128,9 @@ class VggReplica:
         # Gram matrices and their loss terms hang off the conv chain as leaves: with kept
         # (dedicated) tap buffers they run on a side stream beside the following layers.
         self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
+        # (A second side stream for alternate taps was measured 3 % SLOWER per training step: every extra
+        # stream is another hardware queue for the graph's branches to hop between.)
+        self._side2 = None
         self._style_job = None
         self._deferred = []  # (event at the fork point, job) not yet issued on the side stream
         self._style_done = {}  # style layer index (or 'tv') -> event on the side stream after its loss term and gradient
@@ -212,9 +215,9 @@ class VggReplica:
         """Launches the side-stream jobs whose fork point has been passed.  A captured graph keeps
         the first-issued successor of a node on the node's own hardware queue, so the chain's next
         kernel goes first and the side job second."""
-        for ev, job in self._deferred:
-            self._side.wait_event(ev)
-            with torch.cuda.stream(self._side):
+        for ev, job, stream in self._deferred:
+            stream.wait_event(ev)
+            with torch.cuda.stream(stream):
                 job()
         self._deferred.clear()
 
@@ -236,7 +239,8 @@ class VggReplica:
                 # issued after the chain's next kernel (see _flush_side); it waits only for this point
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
-                self._deferred.append((ev, lambda: self._gram_job(li, tensor)))
+                stream = self._side2 if (li & 1) and self._side2 is not None else self._side
+                self._deferred.append((ev, lambda: self._gram_job(li, tensor), stream))
             else:
                 self._gram_job(li, tensor)
         if name == self.content_name and tensor.data_ptr() != self.content.data_ptr():
@@ -281,14 +285,21 @@ class VggReplica:
                 torch.cuda.current_stream().wait_event(ev)
 
         self._style_done.clear()
+        tv_fork = None
         if self._side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._deferred.append((ev, tv))
+            tv_fork = torch.cuda.Event()
+            tv_fork.record(torch.cuda.current_stream())
         else:
             tv()
         self.forward(x_f32, style_job=style_term)
         self._style_job = None
+        if tv_fork is not None:
+            # the TV gradient joins the chain at its very end: it goes BEHIND the style jobs, on the stream
+            # whose last job is not the one the backward pass needs first
+            tv_stream = self._side2 if self._side2 is not None else self._side
+            tv_stream.wait_event(tv_fork)
+            with torch.cuda.stream(tv_stream):
+                tv()
         if content_stream is not None:
             torch.cuda.current_stream().wait_stream(content_stream)
         cnt = self.content.numel()
@@ -348,7 +359,8 @@ class VggReplica:
                     g = dx
                     idx -= 2
             idx -= 1
-        if self._side is not None:   # whatever the chain did not meet on its way (nothing, on the training path)
-            torch.cuda.current_stream().wait_stream(self._side)
+        for side in (self._side, self._side2):   # whatever the chain did not meet on its way
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         self._style_done.clear()
         return self.d_image
