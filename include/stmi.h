@@ -138,6 +138,20 @@ int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
                            int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                            int dtype, void* stream);
 
+/* Backward-data of a 3x3 stride-1 layer (as stmi_conv2d_nhwc_dgrad) that also leaves, per tile of dx, the sums the
+ * backward pass of the instance norm BELOW needs (the norm whose output gradient is dx, model_utilities.py:238-239
+ * seen from the back): sum(g * act'(z)) and sum(g * act'(z) * xhat) over the tile's pixels, g = dx after mask and
+ * addend, xhat = (bn_x - mean) * rstd, z = bn_scale * xhat + bn_shift; bn_x is that norm's input (shaped like dx),
+ * bn_stats its [n,c,2] statistics.  rows: fp32 [n, tiles, 2, ci], tiles from stmi_conv2d_dgrad_in_sums_tiles (0: the
+ * kernel for this geometry leaves no sums).  Consumed by stmi_instance_norm_nhwc_bwd_rows, which then needs no
+ * reduction pass over x and dy. */
+int stmi_conv2d_dgrad_in_sums_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_nhwc_dgrad_in_sums(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,
+                                   const void* addend, float alpha,
+                                   const void* bn_x, const float* bn_stats, const float* bn_scale, const float* bn_shift,
+                                   int bn_act, float* rows,
+                                   int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                   int dtype, void* stream);
 /* Gradient w.r.t. W (Conv2DBackpropFilter): dw fp32 [kh,kw,ci,co].  accumulate == 0: dw is
  * overwritten (zeroed here first); accumulate != 0: the gradient is ADDED to dw, which the
  * caller has zeroed (a trainer clears its whole flat gradient buffer once per step). */
@@ -212,6 +226,13 @@ int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stat
                                 void* dx, float* dscale, float* dshift, float* ws,
                                 float eps, int act, int n, int h, int w, int c,
                                 int dtype, void* stream);
+
+/* stmi_instance_norm_nhwc_bwd with the reduction pass replaced by `nrows` partial rows per sample
+ * ([n, nrows, 2, c]: sum(g), sum(g * xhat)) that stmi_conv2d_nhwc_dgrad_in_sums left behind. */
+int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float* stats,
+                                     const float* scale, const float* shift,
+                                     void* dx, float* dscale, float* dshift, const float* rows, int nrows,
+                                     int act, int n, int h, int w, int c, int dtype, void* stream);
 
 /* ---- VGG pieces -------------------------------------------------------- */
 /* x*255/2 - mean                                    (vgg.py:11-17)

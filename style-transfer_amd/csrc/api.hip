@@ -1,7 +1,7 @@
 // extern "C" surface of libstmi355.so (declared in include/stmi.h).
 #include <stdarg.h>
 
-#include "common.hpp"
+#include "conv_gemm.hpp"
 
 namespace stmi {
 
@@ -32,7 +32,12 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s,
                   float* tile_stats = nullptr, int tile_stats_ts = 0);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
-                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
+                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
+                    const InBwdSums* bn = nullptr);
+int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
+                     float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
+                     int dtype, hipStream_t s);
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
                       void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s);
 int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
@@ -214,6 +219,30 @@ int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
     return conv_dgrad_impl(dy, w_packed_dgrad, dx, relu_mask, addend, alpha, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
 }
 
+int stmi_conv2d_dgrad_in_sums_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_dgrad_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_nhwc_dgrad_in_sums(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,
+                                   const void* addend, float alpha, const void* bn_x, const float* bn_stats,
+                                   const float* bn_scale, const float* bn_shift, int bn_act, float* rows, int n, int h,
+                                   int w, int ci, int co, int kh, int kw, int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_dgrad_in_sums", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(dy && w_packed_dgrad && dx && bn_x && bn_stats && bn_scale && bn_shift && rows,
+                 "conv2d_nhwc_dgrad_in_sums: null pointer");
+    STMI_REQUIRE(bn_act >= STMI_ACT_NONE && bn_act <= STMI_ACT_SIGMOID, "conv2d_nhwc_dgrad_in_sums: bad activation %d", bn_act);
+    InBwdSums bn;
+    bn.rows = rows;
+    bn.tiles = conv_dgrad_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+    STMI_REQUIRE(bn.tiles > 0, "conv2d_nhwc_dgrad_in_sums: this geometry produces no sums "
+                 "(stmi_conv2d_dgrad_in_sums_tiles returned 0)");
+    bn.x = bn_x; bn.stats = bn_stats; bn.scale = bn_scale; bn.shift = bn_shift; bn.act = bn_act;
+    return conv_dgrad_impl(dy, w_packed_dgrad, dx, relu_mask, addend, alpha, n, h, w, ci, co, kh, kw, stride, dtype,
+                           S(stream), &bn);
+}
+
 int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh,
                            int kw, int stride, int accumulate, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
@@ -306,6 +335,17 @@ int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stat
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd: bad activation %d", act);
     if (n == 0) return STMI_OK;
     return in_bwd_impl(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float* stats, const float* scale,
+                                     const float* shift, void* dx, float* dscale, float* dshift, const float* rows,
+                                     int nrows, int act, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && dy && stats && scale && shift && dx && dscale && dshift && rows && nrows > 0 && n >= 0 && h > 0 &&
+                 w > 0 && c > 0, "instance_norm_nhwc_bwd_rows: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd_rows: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_bwd_rows_impl(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, dtype, S(stream));
 }
 
 int stmi_scale_shift(const float* x, const float* mean, void* y, float scale, long count, int c, int dtype,

@@ -424,8 +424,17 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
     int rc = setup_fwd(p, n, h, w, ci, co, kh, kw, stride);
     if (rc) return rc;
     p.in = x; p.wp = wp; p.out = y; p.out_pre = y_pre; p.bias = bias; p.addend = addend; p.relu = relu;
-    p.tile_stats = tile_stats; p.tile_stats_ts = tile_stats_ts;
+    p.tile_stats = tile_stats; p.tile_stats_ts = tile_stats_ts; p.tile_stats_mode = tile_stats ? 1 : 0;
     return launch_conv_gemm(p, dtype, s);
+}
+
+int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+
+// Tiles per sample of the sums a stride-1 backward-data convolution of this geometry can emit (0: it cannot).
+int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (stride != 1 || kh != 3 || kw != 3) return 0;
+    // backward-data of a 3x3 stride-1 layer is the same gather with the roles of ci and co exchanged
+    return conv_fwd_tile_stats_tiles(n, h, w, co, ci, kh, kw, 1, dtype);
 }
 
 // Tiles per sample of the statistics a forward convolution of this geometry can emit (0: it cannot).
@@ -440,7 +449,8 @@ int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int k
 
 // Backward-data of conv(n,h,w,ci -> co, k, stride): gathers dy, writes dx.
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
-                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s) {
+                    int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
+                    const InBwdSums* bn) {
     int ho, wo, pt, pl;
     same_pads(h, kh, stride, &ho, &pt);
     same_pads(w, kw, stride, &wo, &pl);
@@ -466,8 +476,13 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
                 p.taps[t].dy = (short)(pt - ky); p.taps[t].dx = (short)(pl - kx); p.taps[t].widx = t;
             }
         }
+        if (bn) {
+            p.tile_stats = bn->rows; p.tile_stats_ts = bn->tiles; p.tile_stats_mode = 2;
+            p.bn_x = bn->x; p.bn_stats = bn->stats; p.bn_scale = bn->scale; p.bn_shift = bn->shift; p.bn_act = bn->act;
+        }
         return launch_conv_gemm(p, dtype, s);
     }
+    STMI_REQUIRE(!bn, "conv dgrad: instance-norm sums are produced by stride-1 layers only");
     // Output parity classes: input row = (iy + pt - ky) / stride must be integral, so class (cy, cx) uses the
     // taps with ky = cy + pt, kx = cx + pl (mod stride).  First try all classes in ONE launch of the
     // producer/consumer kernel (each is only 1..4 taps deep: four launches are mostly launch overhead).

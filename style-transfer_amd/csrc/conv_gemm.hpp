@@ -33,18 +33,28 @@ struct ConvGemmParams {
     };
     int nclasses;
     SubGrid cls[4];
-    // Per-tile statistics of the written tensor for a following instance norm (LDS-resident patch kernel
-    // only; nullptr = off): tile_stats[sample][tile of the sample][plane][channel], planes = shift k,
-    // sum(x - k), sum((x - k)^2), pixel count; tile_stats_ts = tiles per sample.  One block writes
-    // four contiguous runs of its channels.
+    // Per-tile sums of the written tensor for the instance norm next to this convolution (LDS-resident patch
+    // kernel only; tile_stats == nullptr: off), so that the norm needs no reduction pass of its own over the
+    // tensor.  tile_stats_ts = tiles per sample.
+    //   mode 1 (forward, the norm FOLLOWS the convolution): tile_stats[sample][tile][plane][channel], planes =
+    //          shift k, sum(y - k), sum((y - k)^2), pixel count
+    //   mode 2 (backward-data, the written tensor is the gradient g w.r.t. the OUTPUT of the norm below, whose
+    //          input bn_x has the written tensor's shape): tile_stats[sample][tile][2][channel] =
+    //          sum(g * act'(z)), sum(g * act'(z) * xhat), xhat = (bn_x - mean) * rstd, z = scale * xhat + shift --
+    //          the partial rows the norm's backward apply pass folds.
     float* tile_stats;
-    int tile_stats_ts;
+    int tile_stats_ts, tile_stats_mode;
+    const void* bn_x;
+    const float *bn_stats, *bn_scale, *bn_shift;  // stats [n][c][2] = (mean, rstd)
+    int bn_act;
 };
 
-// Where one block's statistics go: element (plane, local channel c) is base[plane * C + c].
+// Where one block's sums go (element (plane, local channel c) is base[plane * C + c]) and what they are of.
 struct TileStatsOut {
-    float* base;   // nullptr = no statistics
-    int C, count;
+    float* base;      // nullptr = no statistics
+    int C, count;     // channels of the tensor; pixels of this tile inside the image
+    int mode;         // ConvGemmParams::tile_stats_mode
+    const float* stats_n;  // mode 2: statistics of this block's sample
 };
 
 // Epilogue shared by the kernels.  Accumulator tile (tc, tp) of a wave holds, in lane
@@ -157,10 +167,32 @@ constexpr int conv_stage_tpg(int tc, int tp, int wc, int wp, int lds_bytes) {
     return best;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for the wave's global
+// memory traffic (vmcnt(0)), and on this chip that counter includes STORES until they are acknowledged: placed
+// behind a tile's output stores it would cost their round trip to memory (about 2 us per block, measured).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ float conv_act_grad(float z, int act) {
+    if (act == STMI_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == STMI_ACT_SIGMOID) {
+        const float sg = 1.f / (1.f + __expf(-z));
+        return sg * (1.f - sg);
+    }
+    return 1.f;
+}
+
+// With ts_out.base set the block also leaves per-channel sums over its tile (see ConvGemmParams::tile_stats):
+// the finished values go back into the staging rows, and column-owner threads (consecutive threads =
+// consecutive channels: conflict-free LDS reads, coalesced global loads) add them up over the rows.  That needs
+// a single staging group (TPG == TP) and 8 * NT + ROWS words of LDS behind the staging rows.
 template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, typename PixelOffset>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
                                                   float* stage, PixelOffset pixel_offset,
-                                                  TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0}) {
+                                                  TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0, 0, nullptr}) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BLK_CO = 16 * TC * WC;
     constexpr int STRIDE = BLK_CO + 4;   // floats; +16 bytes keeps the 16-byte writes conflict-free
@@ -178,10 +210,12 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
     const T* __restrict__ addend = (const T*)p.addend;
     const int cl_rd = (tid % LPR) * EPC;
     const bool col_ok = co0 + cl_rd < p.Co;
-    const bool want_stats = ts_out.base != nullptr;   // block-uniform
-    float st_k[EPC], st_1[EPC], st_2[EPC];
-#pragma unroll
-    for (int u = 0; u < EPC; u++) st_k[u] = st_1[u] = st_2[u] = 0.f;
+    const bool want_stats = TPG == TP && ts_out.base != nullptr;   // block-uniform
+    const bool restage = want_stats && (mask || addend || p.relu);  // the sums are of the FINISHED values
+    constexpr int CT = BLK_CO / 4;                                  // column threads per staged row (4 channels each)
+    constexpr int NRG = CT <= NT ? NT / CT : 1;                     // row groups: column thread = (row group, 4 channels)
+    float* part = stage + ROWS * STRIDE;                            // [NRG][2][BLK_CO]
+    int* rowoff = reinterpret_cast<int*>(part + 8 * NT);            // [ROWS] element offset of a staged row, or < 0
 
     f32x4 bias_r[TC];
 #pragma unroll
@@ -209,20 +243,12 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
             }
         }
         __syncthreads();
-        if (want_stats && tp0 == 0) {
-            // shift of the block's sums: the tile's first staged row (in the image or not, it is a
-            // finite value of the right size, and any shift gives the same statistics)
-#pragma unroll
-            for (int u = 0; u < EPC; u += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(stage + cl_rd + u);
-                st_k[u] = t[0]; st_k[u + 1] = t[1]; st_k[u + 2] = t[2]; st_k[u + 3] = t[3];
-            }
-        }
         if (!col_ok) continue;
         for (int rr = tid / LPR; rr < ROWS; rr += RPP) {
             const int w_ = rr / (16 * TPG), rem = rr - w_ * (16 * TPG);
             const int pl = (w_ * TP + tp0 + (rem >> 4)) * 16 + (rem & 15);
             const long off = pixel_offset(pl);
+            if (want_stats && cl_rd == 0) rowoff[rr] = (int)off;   // element offsets fit 31 bits (launcher)
             if (off < 0) continue;
             const long e = off + co0 + cl_rd;
             float v[EPC];
@@ -248,51 +274,85 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
 #pragma unroll
                 for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
             }
-            if (want_stats) {
+            if (restage) {
 #pragma unroll
-                for (int u = 0; u < EPC; u++) {
-                    const float d = v[u] - st_k[u];
-                    st_1[u] += d;
-                    st_2[u] += d * d;
-                }
+                for (int u = 0; u < EPC; u += 4)
+                    *reinterpret_cast<f32x4*>(stage + rr * STRIDE + cl_rd + u) = (f32x4){v[u], v[u + 1], v[u + 2], v[u + 3]};
             }
             store_vec<T, EPC>(out + e, v);
         }
     }
-    if (want_stats) {
-        // fold the RPP row owners of every channel: lanes of a wave first, then the waves through LDS
-        static_assert(LPR <= 64 && 64 % LPR == 0, "a wave holds whole pixel rows");
+    if constexpr (TPG == TP && CT <= NT && NT % CT == 0 && ROWS % NRG == 0 && EPC % 4 == 0) {
+        if (want_stats) {
+            constexpr int RPT = ROWS / NRG;        // staged rows per column thread
+            const int col = (tid % CT) * 4, rg = tid / CT;
+            const bool live = co0 + col < p.Co;    // channel counts are multiples of 4 here (row_store_ok)
+            lds_barrier();                         // row offsets (and finished values) are in LDS
+            // Every LDS read is issued before the first use (a loop that waits per row pays an LDS round
+            // trip for each row: 2 us per block, measured), and the reads are 16 bytes wide: four channels
+            // per thread keep the column phase a fraction of the LDS time of the row phase.
+            f32x4 sv[RPT];
+            int ro[RPT];
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
+            for (int j = 0; j < RPT; j++) {
+                sv[j] = *reinterpret_cast<const f32x4*>(stage + (rg + j * NRG) * STRIDE + col);
+                ro[j] = rowoff[rg + j * NRG];
+            }
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            if (ts_out.mode == 1) {
+                const f32x4 k = *reinterpret_cast<const f32x4*>(stage + col);  // the tile's first pixel: always in the image
 #pragma unroll
-            for (int u = 0; u < EPC; u++) {
-                st_1[u] += __shfl_xor(st_1[u], o, 64);
-                st_2[u] += __shfl_xor(st_2[u], o, 64);
+                for (int j = 0; j < RPT; j++) {
+                    const float m = ro[j] >= 0 ? 1.f : 0.f;   // selects, not branches: the rows stay one straight run
+                    const f32x4 d = (sv[j] - k) * m;
+                    s1 += d;
+                    s2 += d * d;
+                }
+                if (rg == 0 && live) *reinterpret_cast<f32x4*>(ts_out.base + col) = k;
+            } else if (live) {
+                const T* __restrict__ bx = (const T*)p.bn_x;
+                const int c = co0 + col;
+                float mean[4], rstd[4], sc[4], sh[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    mean[u] = ts_out.stats_n[2 * (c + u)];
+                    rstd[u] = ts_out.stats_n[2 * (c + u) + 1];
+                    sc[u] = p.bn_scale[c + u];
+                    sh[u] = p.bn_shift[c + u];
+                }
+                float xv[RPT][4];
+#pragma unroll
+                for (int j = 0; j < RPT; j++) load_vec<T, 4>(bx + (ro[j] >= 0 ? ro[j] : 0) + c, xv[j]);
+#pragma unroll
+                for (int j = 0; j < RPT; j++) {
+                    const float m = ro[j] >= 0 ? 1.f : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float xh = (xv[j][u] - mean[u]) * rstd[u];
+                        const float gg = m * sv[j][u] * conv_act_grad(sc[u] * xh + sh[u], p.bn_act);
+                        s1[u] += gg;
+                        s2[u] += gg * xh;
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(part + (rg * 2 + 0) * BLK_CO + col) = s1;
+            *reinterpret_cast<f32x4*>(part + (rg * 2 + 1) * BLK_CO + col) = s2;
+            lds_barrier();
+            if (tid < 2 * BLK_CO) {
+                const int which = tid / BLK_CO, cc = tid - which * BLK_CO;
+                if (co0 + cc < p.Co) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NRG; j++) a += part[(j * 2 + which) * BLK_CO + cc];
+                    if (ts_out.mode == 1) {
+                        ts_out.base[(1 + which) * ts_out.C + cc] = a;
+                        if (which == 0) ts_out.base[3 * ts_out.C + cc] = (float)ts_out.count;
+                    } else {
+                        ts_out.base[which * ts_out.C + cc] = a;
+                    }
+                }
             }
         }
-        constexpr int NW = NT / 64;
-        __syncthreads();  // the last group's rows are consumed
-        if (lane < LPR) {
-#pragma unroll
-            for (int u = 0; u < EPC; u++) {
-                stage[(wave * 2 + 0) * BLK_CO + cl_rd + u] = st_1[u];
-                stage[(wave * 2 + 1) * BLK_CO + cl_rd + u] = st_2[u];
-            }
-        }
-        __syncthreads();
-        if (tid < BLK_CO && co0 + tid < p.Co) {
-            float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int w_ = 0; w_ < NW; w_++) {
-                a1 += stage[(w_ * 2 + 0) * BLK_CO + tid];
-                a2 += stage[(w_ * 2 + 1) * BLK_CO + tid];
-            }
-            float* o = ts_out.base + tid;
-            o[ts_out.C] = a1;
-            o[2 * ts_out.C] = a2;
-            o[3 * ts_out.C] = (float)ts_out.count;
-        }
-        if (wave == 1 && lane < LPR && col_ok) store_vec<float, EPC>(ts_out.base + cl_rd, st_k);
     }
 }
 
@@ -319,6 +379,16 @@ __device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, co
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wave / WP, wave % WP, lane >> 4, lane & 15, Mz, zoff, HWs);
 }
+
+// Optional extra of a backward-data convolution: per-tile sums for the backward pass of the instance norm
+// whose OUTPUT gradient the convolution writes (ConvGemmParams::tile_stats, mode 2).
+struct InBwdSums {
+    float* rows;      // [n][tiles][2][channels]
+    int tiles;
+    const void* x;    // the norm's input, shaped like the written gradient
+    const float *stats, *scale, *shift;
+    int act;
+};
 
 // Name (as a profiler prints it) of the conv kernel launched last by this thread.
 void set_last_conv_kernel(const char* name);

@@ -329,13 +329,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     // epilogue
     const long img = (long)n * H;
     if (p.row_store_ok) {
-        TileStatsOut ts_out{nullptr, 0, 0};
+        TileStatsOut ts_out{nullptr, 0, 0, 0, nullptr};
         if (p.tile_stats) {
             const int ts = (int)(p.pt_div[1] * p.pt_div[2]);
             const int tile_in_sample = (ty0 / PH) * (int)p.pt_div[1] + tx0 / PW;
-            ts_out.base = p.tile_stats + (((long)n * ts + tile_in_sample) * 4) * p.Co + co0;
+            const int planes = p.tile_stats_mode == 1 ? 4 : 2;
+            ts_out.base = p.tile_stats + (((long)n * ts + tile_in_sample) * planes) * p.Co + co0;
             ts_out.C = p.Co;
             ts_out.count = min(PH, H - ty0) * min(PW, W - tx0);
+            ts_out.mode = p.tile_stats_mode;
+            ts_out.stats_n = p.bn_stats ? p.bn_stats + (long)n * p.Co * 2 : nullptr;
         }
         conv_epilogue_lds<T, TC, TP, 2, 2, 512, TP>(p, acc, co0, reinterpret_cast<float*>(lds), [&](int pl) -> long {
             const int f = pl >> 4;

@@ -280,14 +280,47 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
         }
         __syncthreads();
     } else if constexpr (SRC == 2) {
+        // Tile sums are moved to ONE shift per channel (the first tile's), which makes them plain sums: with
+        // d = k_t - k_0,  sum(x - k_0) = s1_t + n_t d,  sum((x - k_0)^2) = s2_t + 2 d s1_t + n_t d^2.
+        // Thread = (tile group, channel): loads are coalesced over channels and all in flight.
+        float* sums = sh + 2 * g.C;         // [2C]
+        float* tmp = sums + 2 * g.C;        // [256]
+        const int W = g.C < 256 ? g.C : 256, G = 256 / W;
+        for (int c0 = 0; c0 < g.C; c0 += W) {
+            const int rg = tid / W, c = c0 + tid % W;
+            float a1 = 0.f, a2 = 0.f;
+            if (rg < G && c < g.C) {
+                const float k0 = tile_row(src, n, 0, g.C, ts)[c];
+#pragma unroll 4
+                for (int t = rg; t < ts; t += G) {
+                    const float* r = tile_row(src, n, t, g.C, ts);
+                    const float d = r[c] - k0, s1 = r[g.C + c], s2 = r[2 * g.C + c], ct = r[3 * g.C + c];
+                    a1 += s1 + ct * d;
+                    a2 += s2 + 2.f * d * s1 + ct * d * d;
+                }
+            }
+            for (int which = 0; which < 2; which++) {
+                if (rg < G) tmp[rg * W + tid % W] = which ? a2 : a1;
+                __syncthreads();
+                if (tid < W && c0 + tid < g.C) {
+                    float t_ = 0.f;
+                    for (int j = 0; j < G; j++) t_ += tmp[j * W + tid];
+                    sums[which * g.C + c0 + tid] = t_;
+                }
+                __syncthreads();
+            }
+        }
+        const float inv = 1.f / (float)g.HW;
         for (int c = tid; c < g.C; c += 256) {
-            const TileFold f = fold_tiles_serial(src, n, c, g.C, ts);
-            const float rstd = 1.f / sqrtf(fmaxf(f.m2 / f.count, 0.f) + eps);
+            const float k0 = tile_row(src, n, 0, g.C, ts)[c];
+            const float m = sums[c] * inv;
+            const float var = fmaxf(sums[g.C + c] * inv - m * m, 0.f);
+            const float mean = k0 + m, rstd = 1.f / sqrtf(var + eps);
             const float a = scale[c] * rstd;
             sh[c] = a;
-            sh[g.C + c] = shift[c] - f.mean * a;
+            sh[g.C + c] = shift[c] - mean * a;
             if (blockIdx.x == 0) {
-                stats[((long)n * g.C + c) * 2] = f.mean;
+                stats[((long)n * g.C + c) * 2] = mean;
                 stats[((long)n * g.C + c) * 2 + 1] = rstd;
             }
         }
@@ -579,6 +612,31 @@ static int bwd_typed(const void* x, const void* dy, const float* stats, const fl
     });
     STMI_LAUNCH_CHECK("in_bwd kernels");
     return STMI_OK;
+}
+
+// backward with the reduction pass already done elsewhere (a backward-data convolution's epilogue left `nrows`
+// partial rows per sample, [n][nrows][2C]): only the apply pass runs
+template <typename T>
+static int bwd_rows_typed(const void* x, const void* dy, const float* stats, const float* scale, const float* shift,
+                          void* dx, float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h,
+                          int w, int c, hipStream_t s) {
+    InGeom g = make_geom<T>(n, h, w, c);
+    g.S = nrows;
+    IN_DISPATCH(T, c, {
+        const int slots = 256 / (c / V);
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, rows, dscale, dshift, (T*)dx, act, g);
+    });
+    STMI_LAUNCH_CHECK("in_bwd_apply_kernel");
+    return STMI_OK;
+}
+
+int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
+                     float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
+                     int dtype, hipStream_t s) {
+    return dtype == STMI_BF16
+               ? bwd_rows_typed<bf16_t>(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, s)
+               : bwd_rows_typed<float>(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, s);
 }
 
 int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '..', 'libstmi355.so')
+LIB_PATH = os.environ.get('STMI_LIB_PATH') or os.path.join(_HERE, '..', 'libstmi355.so')   # STMI_LIB_PATH: tuning builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -34,6 +34,8 @@ SIGNATURES = {
     'stmi_conv2d_to3_supported': (_c_int, [_c_int] * 3),
     'stmi_conv2d_to3_nhwc_fwd': (_c_int, [_vp] * 4 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float] + _CONV + [_c_int, _vp]),
+    'stmi_conv2d_dgrad_in_sums_tiles': (_c_int, [_c_int] * 9),
+    'stmi_conv2d_nhwc_dgrad_in_sums': (_c_int, [_vp] * 5 + [_c_float] + [_vp] * 4 + [_c_int, _vp] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_fwd': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_dgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
@@ -45,6 +47,7 @@ SIGNATURES = {
     'stmi_instance_norm_nhwc_fwd': (_c_int, [_vp, _vp, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_apply_tiles': (_c_int, [_vp, _vp, _c_int, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_bwd_rows': (_c_int, [_vp] * 9 + [_c_int] * 7 + [_vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),
     'stmi_maxpool2x2_same_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_maxpool2x2_same_bwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp]),

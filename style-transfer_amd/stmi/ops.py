@@ -202,8 +202,10 @@ def conv2d_rgb_dgrad(dy, w_packed, k, ci, out=None):
     return dx
 
 
-def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None):
-    """Gradient w.r.t. the conv input of spatial size in_hw; W packed with PACK_DGRAD."""
+def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None, in_bwd=None):
+    """Gradient w.r.t. the conv input of spatial size in_hw; W packed with PACK_DGRAD.
+    in_bwd = (x, stats, scale, shift, act, rows): the instance norm whose OUTPUT gradient this call writes;
+    rows fp32 [n, conv_dgrad_in_sums_tiles(...), 2, ci] receives the sums instance_norm_bwd(..., rows=) folds."""
     kh, kw, ci, co = kshape
     h, w = in_hw
     n = dy.shape[0]
@@ -214,10 +216,28 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
     for t, nm in ((relu_mask, 'relu_mask'), (addend, 'addend')):
         if t is not None:
             _chk(t, nm, dy.dtype, oshape)
+    if in_bwd is not None:
+        bx, bstats, bscale, bshift, bact, rows = in_bwd
+        _chk(bx, 'in_bwd x', dy.dtype, oshape)
+        _chk(bstats, 'in_bwd stats', torch.float32, (n, ci, 2))
+        _chk(bscale, 'in_bwd scale', torch.float32, (ci,))
+        _chk(bshift, 'in_bwd shift', torch.float32, (ci,))
+        _chk(rows, 'in_bwd rows', torch.float32, (n, conv_dgrad_in_sums_tiles(in_hw, n, kshape, stride, dy.dtype), 2, ci))
+        _conv_call('stmi_conv2d_nhwc_dgrad_in_sums',
+                   (dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask), _ptr(addend), float(alpha),
+                    bx.data_ptr(), bstats.data_ptr(), bscale.data_ptr(), bshift.data_ptr(), int(bact), rows.data_ptr(),
+                    n, h, w, ci, co, kh, kw, stride, _dt(dy)), ci, n * h * w, co, kh * kw, stride)
+        return dx
     _conv_call('stmi_conv2d_nhwc_dgrad', (dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
                                           _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy)),
                ci, n * h * w, co, kh * kw, stride)
     return dx
+
+
+def conv_dgrad_in_sums_tiles(in_hw, n, kshape, stride, dtype):
+    """Rows per sample of the instance-norm sums conv2d_dgrad(..., in_bwd=) leaves for this geometry; 0: none."""
+    kh, kw, ci, co = kshape
+    return _lib.load().stmi_conv2d_dgrad_in_sums_tiles(n, in_hw[0], in_hw[1], ci, co, kh, kw, stride, _DT[dtype])
 
 
 def conv2d_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
@@ -355,18 +375,29 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
     return (y, stats, y32) if want_f32 else (y, stats)
 
 
-def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS):
-    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c])."""
+def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS, rows=None):
+    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c]).
+    rows: fp32 [n, r, 2, c] partial sums conv2d_dgrad(..., in_bwd=) left while writing dy; with them the
+    reduction pass over x and dy is skipped."""
     n, h, w, c = x.shape
     _chk(x, 'x')
     _chk(dy, 'dy', x.dtype, x.shape)
     _chk(stats, 'stats', torch.float32, (n, c, 2))
     for t, nm in ((scale, 'scale'), (shift, 'shift'), (dscale, 'dscale'), (dshift, 'dshift')):
         _chk(t, nm, torch.float32, (c,))
-    if ws is None:
+    if ws is None and rows is None:
         ws = instance_norm_ws(n, h, w, c, x.device)
     dx = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
+    if rows is not None:
+        _chk(rows, 'rows', torch.float32)
+        assert rows.dim() == 4 and rows.shape[0] == n and tuple(rows.shape[2:]) == (2, c), tuple(rows.shape)
+
     def launch():
+        if rows is not None:
+            _lib.call('stmi_instance_norm_nhwc_bwd_rows', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), rows.data_ptr(),
+                      rows.shape[1], act, n, h, w, c, _dt(x), _stream())
+            return
         _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
                   shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), ws.data_ptr(), float(eps), act,
                   n, h, w, c, _dt(x), _stream())

@@ -122,14 +122,25 @@ class StylizerNet:
                     b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
                                          device=device)
                     b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
-            # plain convolutions whose kernel can emit per-tile sums of its output: the instance norm
-            # behind them skips its statistics pass.  Off unless STMI_TILE_STATS=1: as measured so far the
-            # epilogue costs the convolution what the statistics pass costs the norm.
+            # plain convolutions whose kernel can emit per-tile sums of its output: the instance norm behind
+            # them skips its statistics pass (STMI_TILE_STATS=0: tuning aid, off)
             b.tile_stats = None
-            if kind == 'conv' and b.rows is None and os.environ.get('STMI_TILE_STATS') == '1':
+            if kind == 'conv' and b.rows is None and os.environ.get('STMI_TILE_STATS', '1') == '1':
                 ts = ops.conv_tile_stats_tiles((batch, h, w, c), b.kshape, s, dtype)
-                if ts > 0:
+                # only where the apply blocks fold the tile rows themselves (<= 32 tiles a sample): with more
+                # tiles the finalize launch and the epilogue cost what the statistics pass costs (measured at
+                # 128 and at 1020 tiles a sample: 21.2 -> 21.1 us and 1021 -> 1026 us per conv + norm pair)
+                if 0 < ts <= 32:
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
+            # ... and in the backward pass the data-gradient kernel of this block can leave the sums the
+            # instance norm of the block BELOW needs (its output gradient is what the kernel writes), so
+            # that norm's backward skips its reduction pass (STMI_IN_SUMS=0: off)
+            b.bwd_rows = None
+            if (training and i > 0 and kind == 'conv' and b.rows is None
+                    and os.environ.get('STMI_IN_SUMS', '1') == '1'):
+                ts = ops.conv_dgrad_in_sums_tiles((h, w), batch, b.kshape, s, dtype)
+                if ts > 0:
+                    self.blocks[i - 1].bwd_rows = torch.zeros((batch, ts, 2, c), dtype=torch.float32, device=device)
             b.fwd_mode, b.bwd_mode = fwd_mode, bwd_mode
             b.W, b.shift, b.scale = self.views[3 * i], self.views[3 * i + 1], self.views[3 * i + 2]
             b.pk = pk
@@ -303,6 +314,7 @@ class StylizerNet:
             self._reader_seq += 1
             self._readers[buf.data_ptr()] = (self._reader_seq, ev)
 
+        have_rows = False   # the previous iteration's data-gradient kernel left the sums of this block's norm
         for i in range(hi, lo - 1, -1):
             b = self.blocks[i]
             x_in = self.blocks[i - 1].y if i > 0 else self.x_in
@@ -311,7 +323,8 @@ class StylizerNet:
             if b.role == 'b':
                 pending_skip = g  # d(block input) receives d(block output) unchanged
             ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act,
-                                  ws=self.ws, out=dconv)
+                                  ws=self.ws, out=dconv, rows=b.bwd_rows if have_rows else None)
+            have_rows = False
             rows_g = None
             if b.kind == 'deconv':
                 wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
@@ -351,7 +364,12 @@ class StylizerNet:
             elif rows_g is not None:
                 ops.conv2d_dgrad(rows_g, b.wp_bwd, (b.k, 1, b.ci, 32), 1, (b.in_h, b.in_w), addend=addend, out=dx)
             else:
-                ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx)
+                below = self.blocks[i - 1]
+                in_bwd = None
+                if below.bwd_rows is not None and i - 1 >= lo:   # the norm below runs in this call
+                    in_bwd = (below.conv_out, below.stats, below.scale, below.shift, below.act, below.bwd_rows)
+                    have_rows = True
+                ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx, in_bwd=in_bwd)
             on_side(w0, wgrad, forked)
             if b.role == 'a':
                 pending_skip = None

@@ -340,6 +340,58 @@ def test_conv_tile_statistics_feed_instance_norm(cuda, dtype, case):
     assert rel_err(y_b, ref) <= TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 16, 32, 128, 'relu', True), (1, 5, 70, 64, 'none', False),
+                                  (2, 11, 40, 64, 'sigmoid', True), (3, 64, 64, 128, 'relu', False)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_dgrad_sums_feed_instance_norm_backward(cuda, dtype, case):
+    """conv2d_dgrad(in_bwd=) + instance_norm_bwd(rows=) against the plain data gradient followed by the
+    three-pass instance-norm backward, and both against the oracle's autograd."""
+    from stmi import ops
+    n, h, w, c, act, use_addend = case
+    actc = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'sigmoid': ops.ACT_SIGMOID}[act]
+    co = 64 if c == 64 else 128
+    x = rnd((n, h, w, c), 1) * 2 + 0.7            # input of the norm below
+    scale, shift = rnd((c,), 2) + 1.5, rnd((c,), 3)
+    wgt = rnd((3, 3, c, co), 4, 0.05)             # the conv above the norm: y2 = conv(act(IN(x)))
+    dy2 = rnd((n, h, w, co), 5)
+    addend = rnd((n, h, w, c), 6) if use_addend else None
+    # oracle: gradient w.r.t. x of  sum(conv(act(IN(x))) * dy2) + sum(act(IN(x)) * addend)
+    xq = q(x, dtype).requires_grad_()
+    sq, hq = scale.float().double().requires_grad_(), shift.float().double().requires_grad_()
+    z = O.instance_norm(xq, sq, hq)
+    y = {'none': z, 'relu': torch.relu(z), 'sigmoid': torch.sigmoid(z)}[act]
+    tot = (O.conv2d_same(y, q(wgt, dtype), 1) * q(dy2, dtype)).sum()
+    if use_addend:
+        tot = tot + (y * q(addend, dtype)).sum()
+    gx, gs, gh = torch.autograd.grad(tot, (xq, sq, hq))
+
+    xd = x.to(cuda, dtype)
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    _, stats = ops.instance_norm_fwd(xd, sd, hd, actc)
+    wp = ops.pack_conv_weights(wgt.to(cuda, torch.float32).contiguous(), ops.PACK_DGRAD, dtype)
+    ts = ops.conv_dgrad_in_sums_tiles((h, w), n, (3, 3, c, co), 1, dtype)
+    assert ts > 0
+    rows = torch.full((n, ts, 2, c), float('nan'), dtype=torch.float32, device=cuda)
+    ad = None if addend is None else addend.to(cuda, dtype)
+    dyd = dy2.to(cuda, dtype)
+    g_a = ops.conv2d_dgrad(dyd, wp, (3, 3, c, co), 1, (h, w), addend=ad, in_bwd=(xd, stats, sd, hd, actc, rows))
+    g_b = ops.conv2d_dgrad(dyd, wp, (3, 3, c, co), 1, (h, w), addend=ad)
+    assert torch.equal(g_a, g_b), 'the sums must not change the data gradient'
+    assert bool(torch.isfinite(rows).all())
+    res = {}
+    for name, kw in (('rows', dict(rows=rows)), ('passes', dict())):
+        dscale, dshift = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+        dx = ops.instance_norm_bwd(xd, g_a, stats, sd, hd, dscale, dshift, actc, **kw)
+        res[name] = (dx, dscale, dshift)
+        assert rel_err(dx, gx) <= (2e-3 if dtype == torch.float32 else 4e-2), name
+        assert rel_err(dscale, gs) <= (1e-3 if dtype == torch.float32 else 2e-2), name
+        assert rel_err(dshift, gh) <= (1e-3 if dtype == torch.float32 else 2e-2), name
+    # the two routes agree with each other more closely than either does with the oracle (the rows are sums
+    # of the fp32 accumulators, the passes read the rounded tensor)
+    assert rel_err(res['rows'][1], res['passes'][1]) <= (1e-4 if dtype == torch.float32 else 1e-2)
+
+
 def test_instance_norm_workspace_is_reusable(cuda):
     """One workspace serves calls of different shapes in a row, and a repeated call gives the same bits."""
     from stmi import ops
