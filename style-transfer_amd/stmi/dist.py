@@ -51,6 +51,8 @@ class FrameStager:
     def upload(self, slot, chunk_np):
         """Host array -> pinned -> device slot (asynchronous once the pinned copy is made)."""
         m = chunk_np.shape[0]
+        if self._used[slot]:
+            self.in_ready[slot].synchronize()      # the slot's previous H2D has left the pinned buffer
         self.pin_in[slot][:m].copy_(torch.from_numpy(chunk_np))
         with torch.cuda.stream(self.h2d):
             if self._used[slot]:

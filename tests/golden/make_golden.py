@@ -1,8 +1,9 @@
 """Generates the committed golden fixtures from the fp64 oracle (oracle/tf_ops.py).
 
 PARITY UNPINNED: the reference holds no golden vectors and TensorFlow cannot run here, so
-these vectors pin the ORACLE against regressions (and are what the HIP path is compared
-with on the GPU); they were not produced by TensorFlow.
+these vectors pin the ORACLE against regressions (tests/test_cpu_oracle.py) and the HIP path
+against the oracle's committed outputs (tests/test_gpu_golden.py); they were not produced by
+TensorFlow.
 
     python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
 """
