@@ -207,8 +207,9 @@ class StylizerNet:
         n = self.n * b.out_h * b.out_w * b.co
         return buf[:n].view(self.n, b.out_h, b.out_w, b.co)
 
-    def forward(self, x_f32):
-        """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32)."""
+    def forward(self, x_f32, between=None):
+        """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32).
+        between(i): optional hook called after the launches of block i (a caller's side work)."""
         self._x_f32 = x_f32
         if not self.blocks[0].rgb:
             ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
@@ -255,6 +256,8 @@ class StylizerNet:
             if b.role == 'b':
                 skip = None
             cur = y
+            if between is not None:
+                between(i)
         return self.out_f32
 
     # -------------------------------------------------------------- backward

@@ -150,13 +150,30 @@ class StyleTrainer:
     def _front(self):
         self._zero.run()
         cs = self._content_stream
-        if cs is not None:
+        order = os.environ.get('STMI_FRONT_ORDER', 'c')
+        if cs is None:
+            self.rep_content.forward(self.batch_in, want_grams=False)
+            out = self.net.forward(self.batch_in)
+        elif order == 'c':
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
                 self.rep_content.forward(self.batch_in, want_grams=False)
+            out = self.net.forward(self.batch_in)
         else:
-            self.rep_content.forward(self.batch_in, want_grams=False)
-        out = self.net.forward(self.batch_in)
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream())
+            cs.wait_event(fork)
+            steps = self.rep_content.forward_steps(self.batch_in, want_grams=False)
+            per = int(order[1:]) if len(order) > 1 else 2
+
+            def some(i):
+                with torch.cuda.stream(cs):
+                    for _ in range(per):
+                        next(steps, None)
+            out = self.net.forward(self.batch_in, between=some if order[0] == 'i' else None)
+            with torch.cuda.stream(cs):
+                for _ in steps:
+                    pass
         d_out = self.rep_loss.loss_and_grad(out, self.style_targets, self.rep_content.content,
                                             self.sw, self.cw, self.tvw, self.losses, content_stream=cs)
         return d_out

@@ -149,6 +149,13 @@ class VggReplica:
 
         style_job(li, tap): optional follow-up of Gram li (its loss term and gradient), launched
         right behind it on the same stream."""
+        for _ in self.forward_steps(x_f32, want_grams, style_job):
+            pass
+        return self.grams, self.content
+
+    def forward_steps(self, x_f32, want_grams=True, style_job=None):
+        """forward() as a generator that yields after every layer's launches, so that a caller can
+        issue the pass in pieces between the launches of another chain."""
         self._want_grams = want_grams
         self._style_job = style_job
         net = self.net
@@ -195,6 +202,7 @@ class VggReplica:
                     self._tap(rname, y)
                     cur = y
                     i += 2
+                    yield
                     continue
                 # last layer of the truncated network: no ReLU follows
                 y = self.content if name == self.content_name else self._buf(self._scratch, shape, (cur,))
@@ -208,8 +216,8 @@ class VggReplica:
                 self._flush_side()
                 cur = y
             i += 1
+            yield
         self._flush_side()
-        return self.grams, self.content
 
     def _flush_side(self):
         """Launches the side-stream jobs whose fork point has been passed.  A captured graph keeps
