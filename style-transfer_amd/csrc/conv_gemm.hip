@@ -521,6 +521,7 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
             m.ntaps = most;
             set_row_store(m, dtype);
             int rc = STMI_OK;
+            if (try_launch_conv_up2(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
             if (try_launch_conv_gemm_pc_multi(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
         }
     }

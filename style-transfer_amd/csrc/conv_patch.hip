@@ -27,6 +27,19 @@ namespace stmi {
 
 __device__ uint4 g_patch_zero_page[8];  // zero-initialised: source of out-of-image rows
 
+#ifdef STMI_STAMPS
+// tuning aid (`make stamps`, scripts/patch_stamps.py; not in the product build): phase time stamps of the
+// first 256 blocks, consumer wave 0 and producer wave 4: 100 MHz wall counter and shader cycle counter
+__device__ unsigned long long g_stamps[256 * 16];
+#define STMI_STAMP(i)                                                                   \
+    if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 4) && blockIdx.x < 256) { \
+        g_stamps[blockIdx.x * 16 + ((threadIdx.x >> 6) ? 8 : 0) + 2 * (i)] = wall_clock64();   \
+        g_stamps[blockIdx.x * 16 + ((threadIdx.x >> 6) ? 8 : 0) + 2 * (i) + 1] = clock64();    \
+    }
+#else
+#define STMI_STAMP(i)
+#endif
+
 
 namespace {
 
@@ -135,6 +148,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     const int n = (int)n_img;
     const int nchunks = p.klen / BK;
 
+    STMI_STAMP(0);
     f32x4 acc[TC][TP];
 #pragma unroll
     for (int a = 0; a < TC; a++)
@@ -202,6 +216,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 #pragma unroll
         for (int s = 1; s < NSW - 1; s++) stage_weights(s, 0, s);
 
+        STMI_STAMP(1);
         int slot = 0;  // ring slot of the current step
         auto chunk_body = [&](auto last_tag, int c) {
             constexpr bool LAST = decltype(last_tag)::value;
@@ -223,6 +238,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c);
         }
         chunk_body(std::true_type{}, nchunks - 1);
+        STMI_STAMP(2);
     } else {
         // ------------------------------------------------------------------ consumer waves
         const int wc = wave >> 1, wpx = wave & 1;
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         auto tap_step = [&](int c, int t, unsigned pbuf) {
             if (c == 0 && t == 0) wait_vmcnt<0>();  // own share of the first patch
             __builtin_amdgcn_s_barrier();
+            if (c == 0 && t == 0) { STMI_STAMP(1); }
             asm volatile("" ::: "memory");
             const Tap tap = p.taps[t];
             const int shift = tap.dy * PWH + tap.dx;
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             }
         }
         mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
+        STMI_STAMP(2);
     }
 
     // epilogue
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
         });
     }
+    STMI_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------
@@ -468,3 +487,8 @@ bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, in
 
 }  // namespace stmi
 
+#ifdef STMI_STAMPS
+extern "C" int stmi_debug_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(stmi::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
