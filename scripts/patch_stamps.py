@@ -21,11 +21,15 @@ for name, h, w, ci, co in LAYERS:
     wt = torch.randn((3, 3, ci, co), device=dev) * (2.0 / (9 * ci)) ** 0.5
     wp = ops.pack_conv_weights(wt, ops.PACK_FWD, torch.bfloat16)
     y = torch.empty((B, h, w, co), device=dev, dtype=torch.bfloat16)
+    tiles = None
+    if os.environ.get('TS') == '1':     # with the epilogue's tile statistics
+        ts = ops.conv_tile_stats_tiles(x.shape, (3, 3, ci, co), 1, torch.bfloat16)
+        tiles = torch.zeros((B, ts, 4, co), dtype=torch.float32, device=dev) if ts > 0 else None
     for _ in range(5):
-        ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, out=y)
+        ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, out=y, tile_stats=tiles)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, out=y); e1.record(); torch.cuda.synchronize()
+    e0.record(); ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, out=y, tile_stats=tiles); e1.record(); torch.cuda.synchronize()
     st = np.zeros(256 * 16, np.uint64)
     assert L.stmi_debug_stamps(st.ctypes.data, st.size) == 0
     st = st.reshape(256, 2, 4, 2).astype(np.float64)      # block, role (consumer/producer), stamp, (wall, cycles)

@@ -409,6 +409,10 @@ bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, 
 // the multi-class form of the launch (p.nclasses parity classes); false when it does not fit.
 bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
+// Stride-2 backward-data / transposed 3x3 convolution with the input patch resident in LDS (conv_up2.hip), for
+// the multi-class form of the launch (p.nclasses parity classes); false when it does not fit.
+bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
+
 // 3x3 stride-1 kernel with the input patch resident in LDS (conv_patch.hip).  Returns true
 // and launches when the problem fits it; name (optional) receives the kernel's name as a
 // profiler prints it.

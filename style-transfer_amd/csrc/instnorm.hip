@@ -502,8 +502,14 @@ static int pick_v(int c) {
 constexpr int kInFoldFloats = 8192;
 constexpr int kInFoldMaxRows = 64;
 
+// Planes of 8 MB and more (the 1080p activations): the pass is bound by bytes there, and the few long blocks
+// that suit the fold (32 a sample at 128 channels: 8 waves a CU) leave the loads of a CU too thin to
+// stream; the forward statistics pass then takes as many slices as the workspace holds and a finalize launch
+// (measured at 16 x 270 x 480 x 128: 184 -> 120 us).
+constexpr long kInBigPlaneBytes = 8L << 20;
+
 template <typename T>
-static InGeom make_geom(int n, int h, int w, int c) {
+static InGeom make_geom(int n, int h, int w, int c, bool fwd_stats = false) {
     InGeom g;
     g.N = n; g.HW = h * w; g.C = c;
     const int v = pick_v<T>(c) > 0 ? pick_v<T>(c) : 1;
@@ -511,6 +517,7 @@ static InGeom make_geom(int n, int h, int w, int c) {
     long s = ((long)g.HW + slots * kInPpt - 1) / (slots * kInPpt);  // one round of loads per thread
     long cap = kInFoldFloats / (2L * c);
     if (cap > kInFoldMaxRows) cap = kInFoldMaxRows;
+    if (fwd_stats && (long)g.HW * c * (long)sizeof(T) >= kInBigPlaneBytes) cap = kInMaxSplits;
     if (cap < 1) cap = 1;
     if (s > cap) s = cap;
     if (s < 1) s = 1;
@@ -541,7 +548,7 @@ long in_ws_floats(int n, int h, int w, int c) { return partial_floats(n, c) + (l
 
 template <typename T>
 static int stats_typed(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, hipStream_t s) {
-    const InGeom g = make_geom<T>(n, h, w, c);
+    const InGeom g = make_geom<T>(n, h, w, c, true);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
@@ -587,13 +594,18 @@ static int apply_typed(const void* x, float* stats, int src_kind, const float* s
 template <typename T>
 static int fwd_typed(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
                      const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c, hipStream_t s) {
-    const InGeom g = make_geom<T>(n, h, w, c);
+    const InGeom g = make_geom<T>(n, h, w, c, true);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_stats_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, ws, g);
     });
     STMI_LAUNCH_CHECK("in_stats_kernel");
+    if (g.S > kInFoldMaxRows) {   // too many rows for the apply blocks to fold: one finalize launch
+        hipLaunchKernelGGL((in_stats_finalize_kernel<T>), dim3(n, (c + 7) / 8), dim3(256), 0, s, (const T*)x, ws, stats, eps, g);
+        STMI_LAUNCH_CHECK("in_stats_finalize_kernel");
+        return apply_typed<T>(x, stats, 0, nullptr, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
+    }
     return apply_typed<T>(x, stats, 1, ws, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
 }
 
