@@ -253,6 +253,34 @@ def test_conv_transpose(cuda, dtype, case):
     assert rel_err(dw, gw_ref) <= TOL[dtype]
 
 
+UP2_CASES = [(2, 9, 37, 64, 32, 18, 74),     # (n, h, w, ci, co, out_h, out_w): transposed conv 64 -> 32, clipped tiles
+             (1, 8, 33, 128, 64, 16, 66),   # 128 -> 64
+             (2, 5, 40, 128, 64, 9, 79),    # odd output: backward-data of a stride-2 conv over a 9 x 79 input
+             (1, 4, 32, 64, 64, 8, 64),     # exactly one tile
+             (1, 70, 50, 64, 32, 140, 100)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', UP2_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_stride2_dgrad_patch_kernel(cuda, dtype, case):
+    """Backward-data of a 3x3 stride-2 SAME convolution (= the transposed convolution of the stylizer's
+    up-sampling blocks) on the LDS-resident-patch kernel, against the oracle's autograd."""
+    from stmi import ops
+    n, h, w, cg, cx, oh, ow = case       # gathered tensor dy [n,h,w,cg], written tensor dx [n,oh,ow,cx]
+    k, s = 3, 2
+    wt = rnd((k, k, cx, cg), 2, 1.0 / np.sqrt(k * k * cg))      # HWIO of the forward conv cx -> cg
+    dy = rnd((n, h, w, cg), 3)
+    xq = torch.zeros((n, oh, ow, cx), dtype=torch.float64, requires_grad=True)
+    y_ref = O.conv2d_same(xq, q(wt, dtype), s)
+    assert tuple(y_ref.shape) == (n, h, w, cg)
+    (ref,) = torch.autograd.grad(y_ref, xq, q(dy, dtype))
+    wd = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    dyd = dy.to(cuda, dtype)
+    got = ops.conv2d_dgrad(dyd, wd, (k, k, cx, cg), s, (oh, ow), alpha=0.5)
+    assert 'conv_up2_kernel' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    assert rel_err(got, 0.5 * ref) <= TOL[dtype]
+
+
 IN_CASES = [(2, 9, 7, 32, 'relu', False), (2, 16, 16, 128, 'none', True), (1, 12, 10, 3, 'sigmoid', False),
             (1, 40, 30, 64, 'relu', False), (1, 64, 48, 128, 'relu', False),
             (4, 64, 64, 128, 'none', True),      # the residual-block shape of the training step
