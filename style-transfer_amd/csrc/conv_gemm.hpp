@@ -22,6 +22,7 @@ struct ConvGemmParams {
     int relu;
     int row_store_ok;  // Co and the tensors' alignment allow whole-row 16-byte stores (set by the launcher)
     unsigned pt_div[3], pt_magic[3];  // patch kernel: channel tiles, tiles per row, tile rows per image (+ reciprocals)
+    unsigned pt_npers;                // persistent patch kernel: tiles of the launch
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the
@@ -189,7 +190,10 @@ __device__ __forceinline__ float conv_act_grad(float z, int act) {
 // the finished values go back into the staging rows, and column-owner threads (consecutive threads =
 // consecutive channels: conflict-free LDS reads, coalesced global loads) add them up over the rows.  That needs
 // a single staging group (TPG == TP) and 8 * NT + ROWS words of LDS behind the staging rows.
-template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, typename PixelOffset>
+// LDSB: the block's barriers wait for LDS traffic only (lds_barrier), for a caller whose other waves are
+// busy loading and must not wait for this tile's output stores; the caller then guarantees that no LDS-DMA
+// targets the staging rows.
+template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, bool LDSB = false, typename PixelOffset>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
                                                   float* stage, PixelOffset pixel_offset,
                                                   TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0, 0, nullptr}) {
@@ -230,7 +234,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
     }
 #pragma unroll
     for (int tp0 = 0; tp0 < TP; tp0 += TPG) {
-        __syncthreads();  // operand tiles (first group) or the previous group's rows are consumed
+        if constexpr (LDSB) lds_barrier();
+        else __syncthreads();  // operand tiles (first group) or the previous group's rows are consumed
         if (wave < WC * WP) {
 #pragma unroll
             for (int tc = 0; tc < TC; tc++) {
@@ -242,7 +247,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
                 }
             }
         }
-        __syncthreads();
+        if constexpr (LDSB) lds_barrier();
+        else __syncthreads();
         if (!col_ok) continue;
         for (int rr = tid / LPR; rr < ROWS; rr += RPP) {
             const int w_ = rr / (16 * TPG), rem = rr - w_ * (16 * TPG);

@@ -376,6 +376,286 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
 }
 
 // ---------------------------------------------------------------------------
+// Persistent form for layers of several block rounds per CU (1080p frames, 512 x 512 Gatys images, the first VGG
+// layers of a training batch).  With one resident block per CU (88-136 KB of LDS) nothing overlaps a block's
+// prologue (first patch + three weight tiles: 1.3-2.0 us) or its epilogue; here a block walks a list of tiles and
+// the K steps of all its tiles form ONE stream through the same ring: while the MFMA waves stage and store tile i
+// (in staging rows of their own, behind the operand buffers), the DMA waves have already issued the first patch
+// and the first weight tiles of tile i + 1.  The DMA waves issue every patch piece themselves (the MFMA waves
+// have no idle prologue to lend), as many pieces as the patch has rows, and join the epilogue's barriers with
+// bare s_barriers.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int pieces_at_pp(int nsw, int pp, int t) {
+    const int span = 11 - nsw;
+    return t < 0 || t >= span ? 0 : pp / span + (t < pp % span ? 1 : 0);
+}
+constexpr int pieces_before_pp(int nsw, int pp, int t) {
+    int n = 0;
+    for (int i = 0; i < t; i++) n += pieces_at_pp(nsw, pp, i);
+    return n;
+}
+constexpr int group_size_pp(int nsw, int ni_w, int pp, bool last, int t) {
+    if (t < 0) return ni_w + pieces_at_pp(nsw, pp, t + 9);
+    if (last) return t + nsw - 1 <= 8 ? ni_w : 0;
+    return ni_w + pieces_at_pp(nsw, pp, t);
+}
+constexpr int in_flight_ok_pp(int nsw, int ni_w, int pp, bool last, int t) {
+    int n = 0;
+    for (int j = 1; j <= nsw - 2; j++) n += group_size_pp(nsw, ni_w, pp, last, t - j);
+    return n;
+}
+}  // namespace
+
+template <typename T, int TC, int PW, int NSW>
+__global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmParams p) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BK = 8 * EPC;
+    constexpr int TP = 4;
+    constexpr int BLK_CO = 32 * TC;
+    constexpr int PH = 128 / PW;
+    constexpr int FPR = PW / 16;
+    constexpr int PWH = PW + 2;
+    constexpr int NROWS = (PH + 2) * PWH;
+    constexpr int NI_W = BLK_CO / 32;
+    constexpr int PP = (NROWS + 31) / 32;                 // 8-row patch pieces per DMA wave and chunk
+    constexpr int W_SLOT = BLK_CO * 128;
+    constexpr int P_BUF = 4 * PP * 8 * 128;
+    constexpr int TPG = TC >= 4 ? 2 : 4;                  // pixel fragments per staging group (about 34 KB of rows)
+    constexpr int EPI_BARRIERS = 2 * (TP / TPG);          // barriers of conv_epilogue_lds for that grouping
+    typedef typename Mma<T>::frag frag;
+
+    extern __shared__ __attribute__((aligned(128))) uint4 lds[];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+    const unsigned patch_base = lds_base + NSW * W_SLOT;
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + NSW * W_SLOT + 2 * P_BUF);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.Hi, W = p.Wi, C = p.Ci;
+    const int nchunks = p.klen / BK;
+
+    // Tiles of this block.  Blocks b and b+8 share an XCD; XCD x walks the contiguous run
+    // [x * total / 8, (x + 1) * total / 8) of the tile order (channel tile fastest, then pixels), its blocks
+    // interleaved: one 4 MiB L2 serves neighbouring tiles at any moment of the launch.
+    const unsigned total = p.pt_npers;
+    const unsigned xcd = blockIdx.x & 7, lane_blk = blockIdx.x >> 3, blk_per_xcd = gridDim.x >> 3;
+    const unsigned run0 = (unsigned)((unsigned long)total * xcd / 8), run1 = (unsigned)((unsigned long)total * (xcd + 1) / 8);
+    const int my_tiles = run0 + lane_blk < run1 ? (int)((run1 - run0 - lane_blk + blk_per_xcd - 1) / blk_per_xcd) : 0;
+    auto div_by = [&](unsigned a, int i) -> unsigned {
+        return p.pt_magic[i] ? __umulhi(a, p.pt_magic[i]) : (p.pt_div[i] == 1 ? a : a / p.pt_div[i]);
+    };
+    struct TilePos { int co0, tx0, ty0, n; };
+    auto tile_pos = [&](int it) -> TilePos {
+        const unsigned tile = run0 + lane_blk + (unsigned)it * blk_per_xcd;
+        const unsigned tp_id = div_by(tile, 0);
+        const unsigned q = div_by(tp_id, 1);
+        const unsigned n_img = div_by(q, 2);
+        return TilePos{(int)(tile - tp_id * p.pt_div[0]) * BLK_CO, (int)(tp_id - q * p.pt_div[1]) * PW,
+                       (int)(q - n_img * p.pt_div[2]) * PH, (int)n_img};
+    };
+    if (my_tiles == 0) return;   // whole block: no barrier has been passed
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ DMA waves
+        const int pw = wave - 4;
+        const int sub = lane >> 3, pos = lane & 7;
+        const T* in = (const T*)p.in;
+        const T* wp = (const T*)p.wp;
+        const T* zero_src = (const T*)(g_patch_zero_page + pos);
+        int wrow_off[NI_W];
+#pragma unroll
+        for (int j = 0; j < NI_W; j++) {
+            const int row = (pw * NI_W + j) * 8 + sub;
+            wrow_off[j] = row * p.kpad + (pos ^ ((row >> 1) & 7)) * EPC;
+        }
+        int co0 = 0;
+        auto stage_weights = [&](int tap_i, int chunk, int slot) {
+            const Tap tap = p.taps[tap_i];
+            const T* wsrc = wp + ((long)tap.widx * p.co_pad + co0) * p.kpad + chunk * BK;
+            const unsigned dst = lds_base + slot * W_SLOT + pw * (NI_W * 1024);
+#pragma unroll
+            for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], dst + j * 1024);
+        };
+        // element offsets of the patch rows this lane fetches in every chunk of a tile, or -1
+        auto patch_offsets = [&](const TilePos& tp, int (&poff)[PP]) {
+            int pr = pw * PP * 8 + sub;
+            const int py0 = pr / PWH;
+            int px = pr - py0 * PWH;
+            int iy = tp.ty0 - 1 + py0, ix = tp.tx0 - 1 + px;
+            const int swz = (pos ^ (sub & 7)) * EPC;
+            const int step = 8 * C, wrap = (W - PWH) * C;
+            int lin = ((tp.n * H + iy) * W + ix) * C + swz;
+#pragma unroll
+            for (int i = 0; i < PP; i++) {
+                const bool ok = pr < NROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                poff[i] = ok ? lin : -1;
+                pr += 8;
+                px += 8;
+                ix += 8;
+                lin += step;
+                const bool w = px >= PWH;
+                px -= w ? PWH : 0;
+                ix -= w ? PWH : 0;
+                iy += w ? 1 : 0;
+                lin += w ? wrap : 0;
+            }
+        };
+        int poff[PP], poff_next[PP];
+        unsigned gc = 0;   // chunks staged so far: selects the patch buffer
+        auto stage_patch_piece = [&](int i, const int (&off)[PP], int chunk, unsigned buf) {
+            const unsigned dst = patch_base + (buf & 1) * P_BUF + (pw * PP + i) * 1024;
+            glds16(off[i] >= 0 ? in + (off[i] + chunk * BK) : zero_src, dst);
+        };
+        TilePos cur = tile_pos(0);
+        co0 = cur.co0;
+        patch_offsets(cur, poff);
+        stage_weights(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PP; i++) stage_patch_piece(i, poff, 0, 0);
+#pragma unroll
+        for (int s = 1; s < NSW - 1; s++) stage_weights(s, 0, s);
+
+        int slot = 0;
+        // chunk c of the current tile; `next_off` / `next_chunk`: where the chunk after it lives (the next
+        // chunk of this tile, or chunk 0 of the next tile); co0_next: the weights' channel tile for that chunk
+        auto chunk_body = [&](auto last_tag, int c, const int (&next_off)[PP], int next_chunk, int co0_next) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            static_for<0, 9>([&](auto t_tag) {
+                constexpr int t = decltype(t_tag)::value;
+                wait_vmcnt<in_flight_ok_pp(NSW, NI_W, PP, LAST, t)>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                constexpr int tn = (t + NSW - 1) % 9, cn = (t + NSW - 1) / 9;
+                if (cn == 0) {
+                    stage_weights(tn, c, slot == 0 ? NSW - 1 : slot - 1);
+                } else if (!LAST) {
+                    const int keep = co0;
+                    co0 = co0_next;
+                    stage_weights(tn, next_chunk, slot == 0 ? NSW - 1 : slot - 1);
+                    co0 = keep;
+                }
+                if (!LAST) {
+#pragma unroll
+                    for (int q = 0; q < pieces_at_pp(NSW, PP, t); q++)
+                        stage_patch_piece(pieces_before_pp(NSW, PP, t) + q, next_off, next_chunk, gc + 1);
+                }
+                slot = slot + 1 == NSW ? 0 : slot + 1;
+            });
+            gc++;
+        };
+        for (int it = 0; it < my_tiles; it++) {
+            const bool has_next = it + 1 < my_tiles;
+            TilePos nxt = cur;
+            if (has_next) {
+                nxt = tile_pos(it + 1);
+                patch_offsets(nxt, poff_next);
+            }
+            for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c, poff, c + 1, co0);
+            if (has_next) {
+                chunk_body(std::false_type{}, nchunks - 1, poff_next, 0, nxt.co0);
+                // the MFMA waves stage and store tile `it`: their barriers need every wave of the block
+#pragma unroll
+                for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < PP; i++) poff[i] = poff_next[i];
+                cur = nxt;
+                co0 = cur.co0;
+            } else {
+                chunk_body(std::true_type{}, nchunks - 1, poff, 0, co0);
+#pragma unroll
+                for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ MFMA waves
+        const int wc = wave >> 1, wpx = wave & 1;
+        const int g = lane >> 4, r16 = lane & 15;
+        int pr_c[TP];
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            const int f = wpx * TP + tp;
+            pr_c[tp] = (f / FPR + 1) * PWH + (f % FPR) * 16 + r16 + 1;
+        }
+        const unsigned a_off = lds_base + wc * TC * 2048 + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
+        f32x4 acc[TC][TP];
+        u32x4 fa[2][TC], fb[2][TP];
+        auto mma_and_read = [&](auto use_tag, unsigned wbase, const unsigned (&baddr)[TP], bool do_read) {
+            constexpr int USE = decltype(use_tag)::value, LOAD = 1 - USE;
+            const unsigned flip = LOAD ? 64u : 0u;
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) {
+#pragma unroll
+                for (int tp = 0; tp < TP; tp++) {
+                    Mma<T>::mma(__builtin_bit_cast(frag, fa[USE][tc]), __builtin_bit_cast(frag, fb[USE][tp]), acc[tc][tp]);
+                    if (do_read) {
+                        constexpr int RPG = TC * TP >= 16 ? 1 : 2;
+#pragma unroll
+                        for (int k = RPG * (tc * TP + tp); k < RPG * (tc * TP + tp + 1); k++) {
+                            if (k < TC) fa[LOAD][k] = lds_read16(wbase ^ flip, k * 2048);
+                            else if (k < TC + TP) fb[LOAD][k - TC] = lds_read16(baddr[k - TC] ^ flip, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        auto landed = [&](auto half_tag) {
+            constexpr int HALF = decltype(half_tag)::value;
+            lds_wait();
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) lds_landed(fa[HALF][tc]);
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) lds_landed(fb[HALF][tp]);
+        };
+        int slot = 0;
+        unsigned gc = 0;
+        unsigned baddr[TP];
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) baddr[tp] = 0;
+        auto tap_step = [&](int t, unsigned pbuf) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const Tap tap = p.taps[t];
+            const int shift = tap.dy * PWH + tap.dx;
+            const unsigned wbase = a_off + slot * W_SLOT;
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) {
+                const int pr = pr_c[tp] + shift;
+                baddr[tp] = pbuf + pr * 128 + ((g ^ (pr & 7)) << 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);
+            landed(std::integral_constant<int, 0>{});
+            mma_and_read(std::integral_constant<int, 0>{}, wbase, baddr, true);
+            landed(std::integral_constant<int, 1>{});
+            slot = slot + 1 == NSW ? 0 : slot + 1;
+        };
+        for (int it = 0; it < my_tiles; it++) {
+            const TilePos tp0 = tile_pos(it);
+#pragma unroll
+            for (int a = 0; a < TC; a++)
+#pragma unroll
+                for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tc = 0; tc < TC; tc++) fa[1][tc] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) fb[1][tp] = (u32x4){0u, 0u, 0u, 0u};
+            for (int c = 0; c < nchunks; c++, gc++) {
+                const unsigned pbuf = patch_base + (gc & 1) * P_BUF;
+                static_for<0, 9>([&](auto t_tag) { tap_step(decltype(t_tag)::value, pbuf); });
+            }
+            mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
+            const long img = (long)tp0.n * H;
+            conv_epilogue_lds<T, TC, TP, 2, 2, 256, TPG, true>(p, acc, tp0.co0, stage, [&](int pl) -> long {
+                const int f = pl >> 4;
+                const int oy = tp0.ty0 + f / FPR, ox = tp0.tx0 + (f % FPR) * 16 + (pl & 15);
+                return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
+            });
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static bool patch_eligible(const ConvGemmParams& p, int dtype) {
@@ -460,6 +740,67 @@ static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
     }
 }
 
+// Compute units of the current device (the persistent kernel's grid), looked up once per process.
+static int device_cus() {
+    static std::atomic<int> cus{0};
+    int v = cus.load(std::memory_order_acquire);
+    if (v == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        v = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        if (v < 8) v = 8;
+        cus.store(v, std::memory_order_release);
+    }
+    return v;
+}
+
+// The persistent form pays from three block rounds per CU on (measured: 64 rounds, 1080p residual layers,
+// -8 % per launch inside the pipeline, -14 % alone; two rounds, conv2_2 of a training batch: +0.4 % on the step).
+// STMI_PATCH_PERS: fewest rounds that take it, 0 = never.
+static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
+    const int min_rounds = STMI_ENV_INT("STMI_PATCH_PERS", 3);
+    if (min_rounds <= 0 || blk_co < 64 || !p.row_store_ok || p.tile_stats || patch_width(p) > 32) return false;
+    if (dtype != STMI_BF16 && blk_co > 64) return false;   // fp32 fragments + the tile walk do not fit 256 VGPRs
+    if (p.klen == (dtype == STMI_BF16 ? 64 : 32)) return false;   // single-chunk layers keep two resident blocks per CU
+    return patch_tiles(p, blk_co) >= (long)min_rounds * (device_cus() / 8 * 8);
+}
+
+template <typename T, int TC, int PW, int NSW>
+static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
+    constexpr int PH = 128 / PW;
+    constexpr size_t kPatch = (size_t)4 * (((PH + 2) * (PW + 2) + 31) / 32) * 8 * 128;
+    constexpr size_t kStage = (size_t)16 * (TC >= 4 ? 2 : 4) * 2 * (32 * TC + 4) * 4;
+    constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * kPatch + kStage;
+    static_assert(kLds <= 160 * 1024, "operand buffers + staging rows exceed the CU's LDS");
+    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
+    if (!attr_set.load(std::memory_order_acquire)) {
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
+                           "hipFuncSetAttribute(conv_patch_pers_kernel)");
+        if (rc) return rc;
+        attr_set.store(true, std::memory_order_release);
+    }
+    const long tiles = patch_tiles(p, 32 * TC);
+    STMI_REQUIRE(tiles > 0 && tiles < (1L << 31), "conv: tile count out of range");
+    ConvGemmParams q = p;
+    const unsigned div[3] = {(unsigned)(p.co_pad / (32 * TC)), (unsigned)ceil_div(p.Wi, PW), (unsigned)ceil_div(p.Hi, PH)};
+    for (int i = 0; i < 3; i++) {
+        q.pt_div[i] = div[i];
+        const bool fits = div[i] > 1 && (unsigned long)tiles * div[i] < (1UL << 32);
+        q.pt_magic[i] = fits ? (unsigned)(((1UL << 32) + div[i] - 1) / div[i]) : 0u;
+    }
+    q.pt_npers = (unsigned)tiles;
+    const unsigned grid = (unsigned)(device_cus() / 8 * 8);   // a multiple of the eight XCDs; tiles >= 2 * grid here
+    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW>), dim3(grid), dim3(512), kLds, s, q);
+    STMI_LAUNCH_CHECK("conv_patch_pers_kernel");
+    return STMI_OK;
+}
+
+template <typename T, int TC>
+static int launch_patch_pers_w(const ConvGemmParams& p, hipStream_t s) {
+    return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4>(p, s) : launch_patch_pers<T, TC, 16, 4>(p, s);
+}
+
 // Tiles per sample the patch kernel would cut this layer into (the number of statistics rows per sample of
 // ConvGemmParams::tile_stats), or 0 when the layer does not run on the patch kernel with row-wise stores.
 int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype) {
@@ -471,6 +812,14 @@ int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype) {
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
     const int co = patch_blk_co(p, dtype);
+    if (patch_persistent(p, dtype, co)) {
+        if (name)
+            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<%s, %d, %d, 4>(stmi::ConvGemmParams)",
+                     dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p));
+        if (dtype == STMI_BF16) *rc = co == 128 ? launch_patch_pers_w<bf16_t, 4>(p, s) : launch_patch_pers_w<bf16_t, 2>(p, s);
+        else *rc = launch_patch_pers_w<float, 2>(p, s);
+        return true;
+    }
     if (name)
         snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
                  dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),

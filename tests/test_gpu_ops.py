@@ -253,6 +253,42 @@ def test_conv_transpose(cuda, dtype, case):
     assert rel_err(dw, gw_ref) <= TOL[dtype]
 
 
+PERS_CASES = [(3, 130, 250, 128, 64), (3, 126, 260, 128, 128), (2, 254, 250, 64, 64)]   # three block rounds and more
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', PERS_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_patch_persistent(cuda, dtype, case):
+    """3x3 stride-1 layers of two and more block rounds per CU run on the persistent patch kernel (a block walks
+    a list of tiles, the next tile's loads issued under the current tile's epilogue): forward with bias, pre-ReLU
+    copy and ReLU, and backward-data with mask and addend, against the oracle; clipped tiles on both borders."""
+    from stmi import ops
+    n, h, w, ci, co = case
+    if ci * (4 if dtype == torch.float32 else 2) // 128 < 2:
+        pytest.skip('a single 128-byte chunk: not a persistent-kernel layer')
+    x = rnd((n, h, w, ci), 1)
+    wt = rnd((3, 3, ci, co), 2, 1.0 / np.sqrt(9 * ci))
+    bias = rnd((co,), 3)
+    ref_pre = O.conv2d_same(q(x, dtype), q(wt, dtype), 1) + bias
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    y, y_pre = ops.conv2d_fwd(x.to(cuda, dtype), wp, (3, 3, ci, co), 1, bias=bias.to(cuda, torch.float32), relu=True,
+                              want_pre=True)
+    name = ops.last_conv_kernel()
+    if dtype == torch.bfloat16 or co < 128:     # (fp32 128-channel tiles keep the one-tile form: registers)
+        assert 'conv_patch_pers_kernel' in name, name
+    assert rel_err(y_pre, ref_pre) <= TOL[dtype]
+    assert rel_err(y, ref_pre.clamp_min(0)) <= TOL[dtype]
+    # backward-data of the same layer: gathers dy [n,h,w,co], writes dx [n,h,w,ci]
+    dy, mask, add = rnd((n, h, w, co), 4), rnd((n, h, w, ci), 5), rnd((n, h, w, ci), 6)
+    xq = torch.zeros((n, h, w, ci), dtype=torch.float64, requires_grad=True)
+    (gx,) = torch.autograd.grad(O.conv2d_same(xq, q(wt, dtype), 1), xq, q(dy, dtype))
+    ref = 0.5 * gx * (q(mask, dtype) > 0) + q(add, dtype)
+    wd = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    got = ops.conv2d_dgrad(dy.to(cuda, dtype), wd, (3, 3, ci, co), 1, (h, w), relu_mask=mask.to(cuda, dtype),
+                           addend=add.to(cuda, dtype), alpha=0.5)
+    assert rel_err(got, ref) <= TOL[dtype]
+
+
 UP2_CASES = [(2, 9, 37, 64, 32, 18, 74),     # (n, h, w, ci, co, out_h, out_w): transposed conv 64 -> 32, clipped tiles
              (1, 8, 33, 128, 64, 16, 66),   # 128 -> 64
              (2, 5, 40, 128, 64, 9, 79),    # odd output: backward-data of a stride-2 conv over a 9 x 79 input
