@@ -25,6 +25,7 @@ const char* last_conv_kernel();
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
 int pack_weights_multi_impl(const float*, void*, const stmi_pack_desc*, int, int, hipStream_t);
 int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int conv_fwd_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats, float eps, const float* scale,
                         const float* shift, const void* residual, void* y, float* y_f32, int act, int n, int h, int w,
                         int c, int dtype, hipStream_t s);
@@ -170,6 +171,12 @@ int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, in
     if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
     if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
     return conv_fwd_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_fwd_tile_stats_free(n, h, w, ci, co, kh, kw, stride, dtype);
 }
 
 int stmi_conv2d_nhwc_fwd_tile_stats(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,

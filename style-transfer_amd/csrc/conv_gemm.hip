@@ -233,10 +233,12 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     ConvGemmParams p = p_in;
     set_row_store(p, dtype);
     if (p.tile_stats) {
-        const int ts = conv_patch_tiles_per_sample(p, dtype);
+        const int ts = conv_patch_tiles_per_sample(p, dtype, p.tile_stats_mode);
         STMI_REQUIRE(ts > 0 && ts == p.tile_stats_ts,
                      "conv: tile statistics asked for a layer whose kernel does not produce them (tiles %d, caller's %d)",
                      ts, p.tile_stats_ts);
+        STMI_REQUIRE(!conv_patch_stats_free(p, dtype) || !(p.relu || p.mask || p.addend),
+                     "conv: the persistent kernel's tile statistics are those of the plain convolution (no ReLU, mask or addend)");
     }
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_pc(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
@@ -428,23 +430,36 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
     return launch_conv_gemm(p, dtype, s);
 }
 
-int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+static int tile_stats_rows(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int mode);
 
 // Tiles per sample of the sums a stride-1 backward-data convolution of this geometry can emit (0: it cannot).
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
     if (stride != 1 || kh != 3 || kw != 3) return 0;
     // backward-data of a 3x3 stride-1 layer is the same gather with the roles of ci and co exchanged
-    return conv_fwd_tile_stats_tiles(n, h, w, co, ci, kh, kw, 1, dtype);
+    return tile_stats_rows(n, h, w, co, ci, kh, kw, 1, dtype, 2);
 }
 
 // Tiles per sample of the statistics a forward convolution of this geometry can emit (0: it cannot).
 // The answer assumes 16-byte aligned tensors, which is what makes the row-wise epilogue eligible.
-int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+static int tile_stats_rows(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int mode) {
     ConvGemmParams p;
     clear_params(p);
     if (setup_fwd(p, n, h, w, ci, co, kh, kw, stride)) return 0;
     p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
-    return conv_patch_tiles_per_sample(p, dtype);
+    return conv_patch_tiles_per_sample(p, dtype, mode);
+}
+
+int conv_fwd_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    return tile_stats_rows(n, h, w, ci, co, kh, kw, stride, dtype, 1);
+}
+
+// 1 when the forward statistics of this geometry cost the convolution nothing (the persistent kernel leaves them)
+int conv_fwd_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    ConvGemmParams p;
+    clear_params(p);
+    if (setup_fwd(p, n, h, w, ci, co, kh, kw, stride)) return 0;
+    p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    return conv_patch_stats_free(p, dtype);
 }
 
 // Backward-data of conv(n,h,w,ci -> co, k, stride): gathers dy, writes dx.

@@ -423,6 +423,7 @@ bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int*
 // and launches when the problem fits it; name (optional) receives the kernel's name as a
 // profiler prints it.
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
-int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype);
+int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype, int mode = 1);   // mode: ConvGemmParams::tile_stats_mode
+int conv_patch_stats_free(const ConvGemmParams& p, int dtype);
 
 }  // namespace stmi

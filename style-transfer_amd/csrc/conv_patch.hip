@@ -407,7 +407,23 @@ constexpr int in_flight_ok_pp(int nsw, int ni_w, int pp, bool last, int t) {
 }
 }  // namespace
 
-template <typename T, int TC, int PW, int NSW>
+//
+// STATS: the launch also leaves the per-tile sums of ConvGemmParams::tile_stats (mode 1) for the instance norm
+// behind the layer.  The MFMA waves' epilogue is untouched: while they store a staging group's rows, the DMA
+// waves -- idle there, their next loads already issued -- add up the same rows by column (lane = channel x
+// one of 256 / BLK_CO row slices, the slices then added across lanes): one statistics row per tile, as the
+// plain kernel leaves, at 2 % of the launch (1080p residual layers, measured).
+// One float from LDS at a byte address plus an immediate offset (no address arithmetic per row); asm so that
+// the read is not merged or moved over the barriers around it.  The caller waits (lds_wait) before use.
+template <int OFF>
+__device__ __forceinline__ float lds_read_f32_at(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <typename T, int TC, int PW, int NSW, bool STATS>
 __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;
@@ -543,6 +559,90 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
             });
             gc++;
         };
+        // Column sums of the tile the MFMA waves are storing.  A DMA wave owns BLK_CO / 4 channels; its lanes
+        // are (channel, row slice rs): slice rs takes rows rs * RPS .. of every staging group, and the slices
+        // of a channel -- lanes of one wave -- are added with lane exchanges, so a tile leaves ONE statistics
+        // row.  Shift: the tile's first pixel (always inside the image).  The reads are inline asm (see
+        // lds_read16).
+        constexpr int RS = 256 / BLK_CO, ROWS = 16 * TPG * 2, RPS = ROWS / RS, STRIDE = BLK_CO + 4, CPW = BLK_CO / 4;
+        static_assert(RPS == 32, "a row slice is two pixel fragments of a staging group");
+        const int cc = pw * CPW + lane % CPW, rs = lane / CPW;
+        const unsigned stage_addr = lds_base + NSW * W_SLOT + 2 * P_BUF;
+        auto epilogue_barriers = [&](const TilePos& tp) {
+            if constexpr (!STATS) {
+#pragma unroll
+                for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+            } else {
+                float k = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+                // A tile inside the image takes the short path: rows read with immediate offsets (no
+                // address arithmetic) and summed two at a time; validity is worked out only for the tiles
+                // on the bottom and right edges, once per pixel fragment (16 rows: 16 pixels of one line).
+                const bool interior = tp.ty0 + PH <= H && tp.tx0 + PW <= W;
+                const unsigned row0 = stage_addr + (rs * RPS * STRIDE + cc) * 4;
+                // row rr = rs * 32 + j of a group: MFMA wave w_ = rr / (16 TPG), fragment (rr % (16 TPG)) / 16
+                const int w_ = rs * RPS / (16 * TPG), f_in_group = (rs * RPS % (16 * TPG)) >> 4;
+                f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+#pragma unroll
+                for (int gi = 0; gi < TP / TPG; gi++) {
+                    __builtin_amdgcn_s_barrier();   // the previous group's rows are consumed
+                    __builtin_amdgcn_s_barrier();   // this group's rows are staged
+                    asm volatile("" ::: "memory");
+                    float v[RPS];
+                    if (gi == 0) k = lds_read_f32_at<0>(stage_addr + cc * 4);
+                    static_for<0, RPS>([&](auto j_tag) {
+                        constexpr int j = decltype(j_tag)::value;
+                        v[j] = lds_read_f32_at<j * STRIDE * 4>(row0);
+                    });
+                    lds_wait();
+                    asm volatile("" : "+v"(k));
+#pragma unroll
+                    for (int j = 0; j < RPS; j++) asm volatile("" : "+v"(v[j]));
+                    if (interior) {
+                        const f32x2 kk = {k, k};
+#pragma unroll
+                        for (int j = 0; j < RPS; j += 2) {
+                            const f32x2 d = f32x2{v[j], v[j + 1]} - kk;
+                            s1v += d;
+                            s2v += d * d;
+                        }
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int f = w_ * TP + gi * TPG + f_in_group + h;   // pixel fragment of the tile
+                            const int oy = tp.ty0 + f / FPR, ox0 = tp.tx0 + (f % FPR) * 16;
+                            const int nvalid = oy < H ? min(16, W - ox0) : 0;    // may be negative: none
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {
+                                const float ok = j < nvalid ? 1.f : 0.f;
+                                const float d = (v[h * 16 + j] - k) * ok;
+                                s1 += d;
+                                s2 += d * d;
+                                cnt += ok;
+                            }
+                        }
+                    }
+                }
+                if (interior) {
+                    s1 = s1v[0] + s1v[1];
+                    s2 = s2v[0] + s2v[1];
+                    cnt = float(RPS * (TP / TPG));
+                }
+#pragma unroll
+                for (int off = CPW; off < 64; off <<= 1) {
+                    s1 += __shfl_xor(s1, off);
+                    s2 += __shfl_xor(s2, off);
+                    cnt += __shfl_xor(cnt, off);
+                }
+                if (rs == 0 && tp.co0 + cc < p.Co) {
+                    const int tile_in_sample = (tp.ty0 / PH) * (int)p.pt_div[1] + tp.tx0 / PW;
+                    float* row = p.tile_stats + (((long)tp.n * p.tile_stats_ts + tile_in_sample) * 4) * p.Co + tp.co0 + cc;
+                    row[0] = k;
+                    row[p.Co] = s1;
+                    row[2 * p.Co] = s2;
+                    row[3 * p.Co] = cnt;
+                }
+            }
+        };
         for (int it = 0; it < my_tiles; it++) {
             const bool has_next = it + 1 < my_tiles;
             TilePos nxt = cur;
@@ -554,16 +654,14 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
             if (has_next) {
                 chunk_body(std::false_type{}, nchunks - 1, poff_next, 0, nxt.co0);
                 // the MFMA waves stage and store tile `it`: their barriers need every wave of the block
-#pragma unroll
-                for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+                epilogue_barriers(cur);
 #pragma unroll
                 for (int i = 0; i < PP; i++) poff[i] = poff_next[i];
                 cur = nxt;
                 co0 = cur.co0;
             } else {
                 chunk_body(std::true_type{}, nchunks - 1, poff, 0, co0);
-#pragma unroll
-                for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
+                epilogue_barriers(cur);
             }
         }
     } else {
@@ -757,15 +855,34 @@ static int device_cus() {
 // The persistent form pays from three block rounds per CU on (measured: 64 rounds, 1080p residual layers,
 // -8 % per launch inside the pipeline, -14 % alone; two rounds, conv2_2 of a training batch: +0.4 % on the step).
 // STMI_PATCH_PERS: fewest rounds that take it, 0 = never.
-static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
+static bool patch_persistent_shape(const ConvGemmParams& p, int dtype, int blk_co, long tiles) {
     const int min_rounds = STMI_ENV_INT("STMI_PATCH_PERS", 3);
-    if (min_rounds <= 0 || blk_co < 64 || !p.row_store_ok || p.tile_stats || patch_width(p) > 32) return false;
+    if (min_rounds <= 0 || blk_co < 64 || !p.row_store_ok || patch_width(p) > 32) return false;
     if (dtype != STMI_BF16 && blk_co > 64) return false;   // fp32 fragments + the tile walk do not fit 256 VGPRs
     if (p.klen == (dtype == STMI_BF16 ? 64 : 32)) return false;   // single-chunk layers keep two resident blocks per CU
-    return patch_tiles(p, blk_co) >= (long)min_rounds * (device_cus() / 8 * 8);
+    return tiles >= (long)min_rounds * (device_cus() / 8 * 8);
 }
 
-template <typename T, int TC, int PW, int NSW>
+// A geometry whose launches are persistent at ANY batch size (one sample alone has the rounds): there the
+// persistent kernel's DMA waves leave the tile statistics almost for free.  Depends on the plane and the channel
+// counts only, so that a sample's result never depends on the batch it is part of.
+static bool patch_stats_persistent(const ConvGemmParams& p, int dtype) {
+    const int co = patch_blk_co(p, dtype);
+    ConvGemmParams one = p;
+    one.N = 1;
+    return patch_persistent_shape(p, dtype, co, patch_tiles(one, co));
+}
+
+static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
+    if (p.tile_stats) {
+        // forward statistics of a plain convolution only; the decision must not depend on the batch size
+        if (p.tile_stats_mode != 1 || p.mask || p.addend || p.relu) return false;
+        return patch_stats_persistent(p, dtype);
+    }
+    return patch_persistent_shape(p, dtype, blk_co, patch_tiles(p, blk_co));
+}
+
+template <typename T, int TC, int PW, int NSW, bool STATS>
 static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     constexpr int PH = 128 / PW;
     constexpr size_t kPatch = (size_t)4 * (((PH + 2) * (PW + 2) + 31) / 32) * 8 * 128;
@@ -774,7 +891,7 @@ static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     static_assert(kLds <= 160 * 1024, "operand buffers + staging rows exceed the CU's LDS");
     static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
     if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW, STATS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_patch_pers_kernel)");
         if (rc) return rc;
@@ -790,23 +907,32 @@ static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
         q.pt_magic[i] = fits ? (unsigned)(((1UL << 32) + div[i] - 1) / div[i]) : 0u;
     }
     q.pt_npers = (unsigned)tiles;
-    const unsigned grid = (unsigned)(device_cus() / 8 * 8);   // a multiple of the eight XCDs; tiles >= 2 * grid here
-    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW>), dim3(grid), dim3(512), kLds, s, q);
+    unsigned grid = (unsigned)(device_cus() / 8 * 8);   // a multiple of the eight XCDs
+    if ((long)grid > tiles) grid = (unsigned)((tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW, STATS>), dim3(grid), dim3(512), kLds, s, q);
     STMI_LAUNCH_CHECK("conv_patch_pers_kernel");
     return STMI_OK;
 }
 
 template <typename T, int TC>
 static int launch_patch_pers_w(const ConvGemmParams& p, hipStream_t s) {
-    return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4>(p, s) : launch_patch_pers<T, TC, 16, 4>(p, s);
+    if (p.tile_stats)
+        return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, true>(p, s) : launch_patch_pers<T, TC, 16, 4, true>(p, s);
+    return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, false>(p, s) : launch_patch_pers<T, TC, 16, 4, false>(p, s);
 }
 
 // Tiles per sample the patch kernel would cut this layer into (the number of statistics rows per sample of
 // ConvGemmParams::tile_stats), or 0 when the layer does not run on the patch kernel with row-wise stores.
-int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype) {
+int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype, int mode) {
     if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH") || !p.row_store_ok) return 0;
     const int pw = patch_width(p), ph = 128 / pw;
+    (void)mode;
     return ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw);
+}
+
+// 1 when the statistics rows of this geometry come at no cost to the launch (the persistent kernel)
+int conv_patch_stats_free(const ConvGemmParams& p, int dtype) {
+    return patch_eligible(p, dtype) && !STMI_ENV_SET("STMI_NO_PATCH") && p.row_store_ok && patch_stats_persistent(p, dtype);
 }
 
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
@@ -814,8 +940,8 @@ bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, in
     const int co = patch_blk_co(p, dtype);
     if (patch_persistent(p, dtype, co)) {
         if (name)
-            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<%s, %d, %d, 4>(stmi::ConvGemmParams)",
-                     dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p));
+            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
+                     dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p), p.tile_stats ? "true" : "false");
         if (dtype == STMI_BF16) *rc = co == 128 ? launch_patch_pers_w<bf16_t, 4>(p, s) : launch_patch_pers_w<bf16_t, 2>(p, s);
         else *rc = launch_patch_pers_w<float, 2>(p, s);
         return true;

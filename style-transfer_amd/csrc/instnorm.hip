@@ -162,56 +162,105 @@ __device__ __forceinline__ TileFold fold_tiles_serial(const float* __restrict__ 
     for (int t = 0; t < ts; t++) {
         const float* r = tile_row(tiles, n, t, C, ts);
         const float ct = r[3 * C + c], s1 = r[C + c], s2 = r[2 * C + c];
-        const float rc = __frcp_rn(ct);
+        const float rc = ct > 0.f ? __frcp_rn(ct) : 0.f;
         const float d = r[c] + s1 * rc - mean;
         m2 += s2 - s1 * s1 * rc + ct * d * d;
     }
     return TileFold{mean, m2, cnt};
 }
 
-// grid (N, ceil(C/16)): 16 channels x 16 tile lanes per block; loads are 64-byte runs of channels
+// Statistics from long tile rows (more than the apply blocks fold themselves), one pass.  Every tile's sums are
+// moved to ONE shift per channel, the first tile's (a pixel of the plane, so (mean - shift)^2 is of the order of
+// the variance and the plain-sum form is as well conditioned as the statistics pass, which shifts by the
+// sample's first pixel too); rows with a zero count add nothing.
+// grid (N, C / CPB): a block owns CPB channels of one sample, a thread one channel quad of every TL-th tile
+// (TL = 1024 / CPB tile lanes).  Sixteen-byte loads, eight tiles (32 loads) of a thread in flight at once: the
+// rows are read at memory speed, not at one round trip per tile.  C must be a multiple of CPB.  (CPB 8 and 32
+// take the same time on 16 x 1020 rows of 128 channels; 8 keeps small batches spread over more blocks.)
+template <int CPB>
 __global__ __launch_bounds__(256) void in_stats_from_tiles_kernel(const float* __restrict__ tiles,
                                                                   float* __restrict__ stats, float eps, int C, int ts) {
-    __shared__ float red[3][16][17];
-    const int n = blockIdx.x, cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 16 + cl;
+    constexpr int QN = CPB / 4, TL = 256 / QN;
+    __shared__ f32x4 red[3][TL][QN + 1];
+    const int n = blockIdx.x, q = threadIdx.x % QN, tl = threadIdx.x / QN;
+    const int c = blockIdx.y * CPB + q * 4;
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(tile_row(tiles, n, 0, C, ts) + c);
+    f32x4 cnt = {0.f, 0.f, 0.f, 0.f}, s1 = cnt, s2 = cnt;
+    constexpr int U = 8;
+    for (int t0 = tl; t0 < ts; t0 += TL * U) {
+        f32x4 k[U], a[U], b[U], ct[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * TL;
+            const bool ok = t < ts;
+            const float* r = tile_row(tiles, n, ok ? t : 0, C, ts) + c;
+            k[u] = *reinterpret_cast<const f32x4*>(r);
+            a[u] = *reinterpret_cast<const f32x4*>(r + C);
+            b[u] = *reinterpret_cast<const f32x4*>(r + 2 * C);
+            ct[u] = *reinterpret_cast<const f32x4*>(r + 3 * C);
+            if (!ok) ct[u] = a[u] = b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const f32x4 d = k[u] - k0;
+            cnt += ct[u];
+            s1 += a[u] + ct[u] * d;
+            s2 += b[u] + 2.f * d * a[u] + ct[u] * d * d;
+        }
+    }
+    red[0][tl][q] = cnt;
+    red[1][tl][q] = s1;
+    red[2][tl][q] = s2;
+    __syncthreads();
+    if (threadIdx.x < CPB) {
+        const int qq = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float tc = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < TL; j++) {
+            tc += red[0][j][qq][e];
+            t1 += red[1][j][qq][e];
+            t2 += red[2][j][qq][e];
+        }
+        const int ch = blockIdx.y * CPB + threadIdx.x;
+        const float m = t1 / tc;
+        stats[((long)n * C + ch) * 2] = tile_row(tiles, n, 0, C, ts)[ch] + m;
+        stats[((long)n * C + ch) * 2 + 1] = 1.f / sqrtf(fmaxf(t2 / tc - m * m, 0.f) + eps);
+    }
+}
+
+// The same for any channel count: 8 channels x 32 tile lanes per block, four-byte loads.
+__global__ __launch_bounds__(256) void in_stats_from_tiles_any_kernel(const float* __restrict__ tiles,
+                                                                      float* __restrict__ stats, float eps, int C, int ts) {
+    __shared__ float red[3][32][9];
+    const int n = blockIdx.x, cl = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 8 + cl;
     const bool live = c < C;
     const int cc = live ? c : 0;
     const float k0 = tile_row(tiles, n, 0, C, ts)[cc];
-    float cnt = 0.f, s = 0.f;
-    for (int t = tl; t < ts; t += 16) {
+    float cnt = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int t = tl; t < ts; t += 32) {
         const float* r = tile_row(tiles, n, t, C, ts);
-        const float ct = r[3 * C + cc];
+        const float ct = r[3 * C + cc], d = r[cc] - k0, a = r[C + cc], b = r[2 * C + cc];
         cnt += ct;
-        s += ct * (r[cc] - k0) + r[C + cc];
+        s1 += a + ct * d;
+        s2 += b + 2.f * d * a + ct * d * d;
     }
     red[0][tl][cl] = cnt;
-    red[1][tl][cl] = s;
-    __syncthreads();
-    cnt = 0.f;
-    s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        cnt += red[0][j][cl];
-        s += red[1][j][cl];
-    }
-    const float mean = k0 + s / cnt;
-    float m2 = 0.f;
-    for (int t = tl; t < ts; t += 16) {
-        const float* r = tile_row(tiles, n, t, C, ts);
-        const float ct = r[3 * C + cc], s1 = r[C + cc], s2 = r[2 * C + cc];
-        const float rc = __frcp_rn(ct);
-        const float d = r[cc] + s1 * rc - mean;
-        m2 += s2 - s1 * s1 * rc + ct * d * d;
-    }
-    red[2][tl][cl] = m2;
+    red[1][tl][cl] = s1;
+    red[2][tl][cl] = s2;
     __syncthreads();
     if (tl == 0 && live) {
-        m2 = 0.f;
+        cnt = s1 = s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; j++) m2 += red[2][j][cl];
-        stats[((long)n * C + c) * 2] = mean;
-        stats[((long)n * C + c) * 2 + 1] = 1.f / sqrtf(fmaxf(m2 / cnt, 0.f) + eps);
+        for (int j = 0; j < 32; j++) {
+            cnt += red[0][j][cl];
+            s1 += red[1][j][cl];
+            s2 += red[2][j][cl];
+        }
+        const float m = s1 / cnt;
+        stats[((long)n * C + c) * 2] = k0 + m;
+        stats[((long)n * C + c) * 2 + 1] = 1.f / sqrtf(fmaxf(s2 / cnt - m * m, 0.f) + eps);
     }
 }
 
@@ -570,7 +619,11 @@ static int apply_typed(const void* x, float* stats, int src_kind, const float* s
                        int n, int h, int w, int c, hipStream_t s) {
     const InGeom g = make_geom<T>(n, h, w, c);
     if (src_kind == 2 && ts > kFoldMaxTiles) {
-        hipLaunchKernelGGL(in_stats_from_tiles_kernel, dim3(n, (c + 15) / 16), dim3(256), 0, s, src, stats, eps, c, ts);
+        // the launch shape depends on the channel count only: a sample's statistics must not depend on its batch
+        if (c % 8 == 0)
+            hipLaunchKernelGGL(in_stats_from_tiles_kernel<8>, dim3(n, c / 8), dim3(256), 0, s, src, stats, eps, c, ts);
+        else
+            hipLaunchKernelGGL(in_stats_from_tiles_any_kernel, dim3(n, (c + 7) / 8), dim3(256), 0, s, src, stats, eps, c, ts);
         src_kind = 0;
     }
     IN_DISPATCH(T, c, {

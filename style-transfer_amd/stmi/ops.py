@@ -134,6 +134,13 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
     return (y, pre) if want_pre else y
 
 
+def conv_tile_stats_free(x_shape, kshape, stride, dtype):
+    """True when the statistics rows of this geometry cost the convolution nothing (the persistent kernel)."""
+    n, h, w, ci = x_shape
+    kh, kw, _, co = kshape
+    return bool(_lib.load().stmi_conv2d_tile_stats_free(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
 def conv_tile_stats_tiles(x_shape, kshape, stride, dtype):
     """Tiles per sample of the statistics conv2d_fwd(..., tile_stats=) emits for this geometry; 0 when the
     kernel that runs it emits none (then instance_norm_fwd makes its own statistics pass)."""

@@ -130,7 +130,9 @@ class StylizerNet:
                 # only where the apply blocks fold the tile rows themselves (<= 32 tiles a sample): with more
                 # tiles the finalize launch and the epilogue cost what the statistics pass costs (measured at
                 # 128 and at 1020 tiles a sample: 21.2 -> 21.1 us and 1021 -> 1026 us per conv + norm pair)
-                if 0 < ts <= int(os.environ.get('STMI_TILE_STATS_MAX', '32')):
+                # ... or where the persistent kernel leaves the rows for free (1080p planes)
+                if 0 < ts <= int(os.environ.get('STMI_TILE_STATS_MAX', '32')) or (
+                        ts > 0 and ops.conv_tile_stats_free((batch, h, w, c), b.kshape, s, dtype)):
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... and in the backward pass the data-gradient kernel of this block can leave the sums the
             # instance norm of the block BELOW needs (its output gradient is what the kernel writes), so

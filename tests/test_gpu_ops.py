@@ -362,6 +362,8 @@ TILE_STAT_CASES = [
     # one tile per sample, many tiles (a finalize launch instead of the fold inside the apply blocks)
     (2, 16, 32, 128, 128), (1, 5, 70, 64, 64), (2, 11, 40, 128, 64), (1, 3, 2, 64, 64), (3, 64, 64, 128, 128),
     (1, 70, 150, 64, 128),
+    (1, 270, 480, 128, 128),    # one sample alone fills three block rounds: the persistent kernel leaves the rows
+    (2, 200, 330, 64, 64),      # ... (fp32: two 128-byte chunks, four row slices per tile)
 ]
 
 
