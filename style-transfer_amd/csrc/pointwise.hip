@@ -297,26 +297,45 @@ int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, 
 // total variation: one thread per element; forward differences to the right
 // and below feed the loss, the gradient gathers the up-to-four differences the
 // element takes part in.
+// A block owns a contiguous span of the flat [n*h][w*c] tensor and walks it U x 256 elements at a time with the
+// loads of all U elements (the value and its four neighbours, mostly cache hits) issued before the first use:
+// the launch is a few memory round trips long, not one per row.  32-bit indices (the launcher checks the count).
 template <typename T>
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, T* __restrict__ grad, float* loss,
-                                                 float wx, float wy, int n, int h, int w, int c) {
+                                                 float wx, float wy, int total, int span, int h, int w, int c) {
     __shared__ float red[4];
-    // a block walks whole image rows: 32-bit index arithmetic, one division per element
-    const int rowst = w * c, rows = n * h;
+    constexpr int U = 4;
+    const int rowst = w * c;
+    const int begin = blockIdx.x * span, end = min(total, begin + span);
     float acc = 0.f;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int y = row % h;
-        const float* r = img + (long)row * rowst;
-        T* gr = grad + (long)row * rowst;
-        for (int j = threadIdx.x; j < rowst; j += 256) {
-            const int x = j / c;
-            const float v = r[j];
+    for (int e0 = begin + (int)threadIdx.x; e0 < end; e0 += 256 * U) {
+        float v[U], right[U], left[U], down[U], up[U];
+        bool has_r[U], has_l[U], has_d[U], has_u[U], live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = e0 + u * 256;
+            live[u] = e < end;
+            const int ee = live[u] ? e : begin;
+            const int row = ee / rowst, j = ee - row * rowst, y = row % h, x = j / c;
+            has_r[u] = x + 1 < w;
+            has_l[u] = x > 0;
+            has_d[u] = y + 1 < h;
+            has_u[u] = y > 0;
+            v[u] = img[ee];
+            right[u] = has_r[u] ? img[ee + c] : 0.f;
+            left[u] = has_l[u] ? img[ee - c] : 0.f;
+            down[u] = has_d[u] ? img[ee + rowst] : 0.f;
+            up[u] = has_u[u] ? img[ee - rowst] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!live[u]) continue;
             float gsum = 0.f;
-            if (x + 1 < w) { const float d = r[j + c] - v; acc += wx * d * d; gsum -= 2.f * wx * d; }
-            if (x > 0) { const float d = v - r[j - c]; gsum += 2.f * wx * d; }
-            if (y + 1 < h) { const float d = r[j + rowst] - v; acc += wy * d * d; gsum -= 2.f * wy * d; }
-            if (y > 0) { const float d = v - r[j - rowst]; gsum += 2.f * wy * d; }
-            gr[j] = from_f32<T>(gsum);
+            if (has_r[u]) { const float d = right[u] - v[u]; acc += wx * d * d; gsum -= 2.f * wx * d; }
+            if (has_l[u]) { const float d = v[u] - left[u]; gsum += 2.f * wx * d; }
+            if (has_d[u]) { const float d = down[u] - v[u]; acc += wy * d * d; gsum -= 2.f * wy * d; }
+            if (has_u[u]) { const float d = v[u] - up[u]; gsum += 2.f * wy * d; }
+            grad[e0 + u * 256] = from_f32<T>(gsum);
         }
     }
     const float tot = block_sum_256(acc, red);
@@ -328,11 +347,17 @@ int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int 
     // reduce_mean over [n,h,w-1,c] and [n,h-1,w,c]; a 1-wide axis gives an empty mean (NaN in TF): treated as 0 here
     const float wx = w > 1 ? weight / ((float)n * h * (w - 1) * c) : 0.f;
     const float wy = h > 1 ? weight / ((float)n * (h - 1) * w * c) : 0.f;
-    const dim3 grid(n * h < 256 ? n * h : 256);  // few blocks: each ends with one atomic on the same address
+    const long count = (long)n * h * w * c;
+    if (count == 0) return STMI_OK;
+    STMI_REQUIRE(count < (1L << 31) - 256 * 8, "tv: more than 2^31 elements");
+    // at most 256 blocks (each ends with one atomic on the same address), spans a multiple of the block's stride
+    const int blocks = (int)(count < 256 * 1024 ? (count + 1023) / 1024 : 256);
+    const int span = (int)(((count + blocks - 1) / blocks + 1023) / 1024 * 1024);
+    const dim3 grid((unsigned)((count + span - 1) / span));
     if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, n, h, w, c);
+        hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, (int)count, span, h, w, c);
     else
-        hipLaunchKernelGGL(tv_kernel<float>, grid, dim3(256), 0, s, img, (float*)grad, loss, wx, wy, n, h, w, c);
+        hipLaunchKernelGGL(tv_kernel<float>, grid, dim3(256), 0, s, img, (float*)grad, loss, wx, wy, (int)count, span, h, w, c);
     STMI_LAUNCH_CHECK("tv_kernel");
     return STMI_OK;
 }
