@@ -99,7 +99,7 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
 int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 /* 1 when the statistics rows of this geometry cost the convolution nothing: planes large enough that ONE sample
  * already runs on the persistent patch kernel, whose loading waves sum the rows while the computing waves store
- * them (then several rows per tile; no ReLU with them).  Otherwise the rows cost the convolution's epilogue
+ * them (no ReLU with them).  Otherwise the rows cost the convolution's epilogue
  * about a microsecond per block and pay only while stmi_instance_norm_nhwc_apply_tiles can fold them without
  * a finalize launch (at most 32 per sample).  No counterpart in the reference (a tuning query). */
 int stmi_conv2d_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
@@ -173,6 +173,15 @@ int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw,
 int stmi_conv2d_transpose_nhwc_fwd(const void* x, const void* w_packed_dgrad, void* y,
                                    int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                    int dtype, void* stream);
+/* The same transposed convolution, also leaving the per-tile sums of y (layout and consumer as described at
+ * stmi_conv2d_tile_stats_tiles) for the instance norm that follows it in deconv_block
+ * (model_utilities.py:245-253: conv2d_transpose, then instance_norm): the norm then needs no statistics pass
+ * over y.  stmi_conv2d_transpose_tile_stats_tiles: rows per sample, 0 when the kernel that runs this geometry
+ * leaves none (then use stmi_conv2d_transpose_nhwc_fwd); tile_stats holds n * tiles * 4 * co floats. */
+int stmi_conv2d_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_transpose_nhwc_fwd_tile_stats(const void* x, const void* w_packed_dgrad, void* y, float* tile_stats,
+                                              int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                              int dtype, void* stream);
 /* dy [n,s*h,s*w,co] -> dx [n,h,w,ci]; W packed with STMI_PACK_FWD, (ci_pack, co_pack) = (co, ci). */
 int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx,
                                      const void* addend,

@@ -34,7 +34,8 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
                   float* tile_stats = nullptr, int tile_stats_ts = 0);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
-                    const InBwdSums* bn = nullptr);
+                    const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0);
+int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
                      float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
@@ -264,6 +265,24 @@ int stmi_conv2d_transpose_nhwc_fwd(const void* x, const void* w_packed_dgrad, vo
     if (check_conv("conv2d_transpose_nhwc_fwd", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && w_packed_dgrad && y, "conv2d_transpose_nhwc_fwd: null pointer");
     return conv_dgrad_impl(x, w_packed_dgrad, y, nullptr, nullptr, 1.f, n, h * stride, w * stride, co, ci, kh, kw, stride, dtype, S(stream));
+}
+
+int stmi_conv2d_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_transpose_nhwc_fwd_tile_stats(const void* x, const void* w_packed_dgrad, void* y, float* tile_stats,
+                                              int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype,
+                                              void* stream) {
+    if (check_conv("conv2d_transpose_nhwc_fwd_tile_stats", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_dgrad && y && tile_stats, "conv2d_transpose_nhwc_fwd_tile_stats: null pointer");
+    const int ts = conv_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+    STMI_REQUIRE(ts > 0, "conv2d_transpose_nhwc_fwd_tile_stats: this geometry produces no tile statistics "
+                 "(stmi_conv2d_transpose_tile_stats_tiles returned 0)");
+    return conv_dgrad_impl(x, w_packed_dgrad, y, nullptr, nullptr, 1.f, n, h * stride, w * stride, co, ci, kh, kw, stride,
+                           dtype, S(stream), nullptr, tile_stats, ts);
 }
 
 int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx, const void* addend, int n,

@@ -83,6 +83,15 @@ __device__ __forceinline__ void load_vec(const T* p, float (&out)[V]) {
     }
 }
 
+// the V = 16 / sizeof(T) elements of a 16-byte register value
+template <typename T, int V>
+__device__ __forceinline__ void unpack_vec(const uint4& raw, float (&out)[V]) {
+    static_assert(sizeof(T) * V == 16, "one 16-byte vector");
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < V; i++) out[i] = to_f32<T>(e[i]);
+}
+
 template <typename T, int V>
 __device__ __forceinline__ void store_vec(T* p, const float (&in)[V]) {
     if constexpr ((sizeof(T) * V) % 16 == 0) {

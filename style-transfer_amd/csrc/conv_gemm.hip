@@ -463,9 +463,53 @@ int conv_fwd_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw
 }
 
 // Backward-data of conv(n,h,w,ci -> co, k, stride): gathers dy, writes dx.
+// The multi-class form of a strided backward-data launch: every output parity class (cy, cx) is a sub-grid with
+// its own taps of the shared table (input row = (iy + pt - ky) / stride must be integral, so class (cy, cx) uses
+// the taps with ky = cy + pt, kx = cx + pl (mod stride)).  p: the launch with everything but the sub-grids set.
+// false: a class has no taps or the table overflows (the caller launches class by class).
+static bool build_multi_class(const ConvGemmParams& p, int h, int w, int kh, int kw, int stride, int pt, int pl,
+                              int dtype, ConvGemmParams& m) {
+    m = p;
+    m.oys = stride; m.oxs = stride;
+    int nt = 0, nc = 0, most = 0;
+    for (int cy = 0; cy < stride; cy++) {
+        for (int cx = 0; cx < stride; cx++) {
+            const int hs = (h - cy + stride - 1) / stride, ws = (w - cx + stride - 1) / stride;
+            if (hs <= 0 || ws <= 0) continue;
+            if (nc >= 4) return false;
+            ConvGemmParams::SubGrid& g2 = m.cls[nc];
+            g2.Hs = hs; g2.Ws = ws; g2.oy0 = cy; g2.ox0 = cx; g2.tap0 = nt; g2.ntaps = 0; g2.tile_end = 0;
+            for (int ky = 0; ky < kh; ky++) {
+                const int ny = cy + pt - ky;
+                if (((ny % stride) + stride) % stride) continue;
+                for (int kx = 0; kx < kw; kx++) {
+                    const int nx = cx + pl - kx;
+                    if (((nx % stride) + stride) % stride) continue;
+                    if (nt >= kMaxTaps) return false;
+                    m.taps[nt].dy = (short)((ny - (((ny % stride) + stride) % stride)) / stride);
+                    m.taps[nt].dx = (short)((nx - (((nx % stride) + stride) % stride)) / stride);
+                    m.taps[nt].widx = ky * kw + kx;
+                    nt++;
+                    g2.ntaps++;
+                }
+            }
+            if (g2.ntaps == 0) return false;   // a class without taps is all zeros: left to the per-class launches
+            if (g2.ntaps > most) { most = g2.ntaps; m.Hs = hs; m.Ws = ws; }
+            nc++;
+        }
+    }
+    if (nc == 0) return false;
+    m.nclasses = nc;
+    m.ntaps = most;
+    set_row_store(m, dtype);
+    return true;
+}
+
+// tile_stats (with tile_stats_ts rows per sample, conv_transpose_tile_stats_tiles): the forward of a transposed
+// convolution also leaves the per-tile sums of dx for the instance norm behind it.
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
-                    const InBwdSums* bn) {
+                    const InBwdSums* bn, float* tile_stats, int tile_stats_ts) {
     int ho, wo, pt, pl;
     same_pads(h, kh, stride, &ho, &pt);
     same_pads(w, kw, stride, &wo, &pl);
@@ -495,51 +539,24 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
             p.tile_stats = bn->rows; p.tile_stats_ts = bn->tiles; p.tile_stats_mode = 2;
             p.bn_x = bn->x; p.bn_stats = bn->stats; p.bn_scale = bn->scale; p.bn_shift = bn->shift; p.bn_act = bn->act;
         }
+        STMI_REQUIRE(!tile_stats, "conv dgrad: forward tile statistics are for the strided (transposed-conv) form");
         return launch_conv_gemm(p, dtype, s);
     }
     STMI_REQUIRE(!bn, "conv dgrad: instance-norm sums are produced by stride-1 layers only");
-    // Output parity classes: input row = (iy + pt - ky) / stride must be integral, so class (cy, cx) uses the
-    // taps with ky = cy + pt, kx = cx + pl (mod stride).  First try all classes in ONE launch of the
-    // producer/consumer kernel (each is only 1..4 taps deep: four launches are mostly launch overhead).
+    // First try all classes in ONE launch (each is only 1..4 taps deep: four launches are mostly launch overhead).
     if (stride * stride <= 4) {
-        ConvGemmParams m = p;
-        m.oys = stride; m.oxs = stride;
-        int nt = 0, nc = 0, most = 0;
-        bool fits = true;
-        for (int cy = 0; cy < stride && fits; cy++) {
-            for (int cx = 0; cx < stride && fits; cx++) {
-                const int hs = (h - cy + stride - 1) / stride, ws = (w - cx + stride - 1) / stride;
-                if (hs <= 0 || ws <= 0) continue;
-                ConvGemmParams::SubGrid& g2 = m.cls[nc];
-                g2.Hs = hs; g2.Ws = ws; g2.oy0 = cy; g2.ox0 = cx; g2.tap0 = nt; g2.ntaps = 0; g2.tile_end = 0;
-                for (int ky = 0; ky < kh; ky++) {
-                    const int ny = cy + pt - ky;
-                    if (((ny % stride) + stride) % stride) continue;
-                    for (int kx = 0; kx < kw; kx++) {
-                        const int nx = cx + pl - kx;
-                        if (((nx % stride) + stride) % stride) continue;
-                        if (nt >= kMaxTaps) { fits = false; break; }
-                        m.taps[nt].dy = (short)((ny - (((ny % stride) + stride) % stride)) / stride);
-                        m.taps[nt].dx = (short)((nx - (((nx % stride) + stride) % stride)) / stride);
-                        m.taps[nt].widx = ky * kw + kx;
-                        nt++;
-                        g2.ntaps++;
-                    }
-                }
-                if (g2.ntaps == 0) { fits = false; break; }   // a class without taps is all zeros: leave it to the loop below
-                if (g2.ntaps > most) { most = g2.ntaps; m.Hs = hs; m.Ws = ws; }
-                nc++;
-            }
-        }
-        if (fits && nc > 0) {
-            m.nclasses = nc;
-            m.ntaps = most;
-            set_row_store(m, dtype);
+        ConvGemmParams m;
+        if (build_multi_class(p, h, w, kh, kw, stride, pt, pl, dtype, m)) {
             int rc = STMI_OK;
+            if (tile_stats) {
+                m.tile_stats = tile_stats; m.tile_stats_ts = tile_stats_ts; m.tile_stats_mode = 1;
+            }
             if (try_launch_conv_up2(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+            STMI_REQUIRE(!tile_stats, "transposed conv: this geometry leaves no tile statistics");
             if (try_launch_conv_gemm_pc_multi(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
         }
     }
+    STMI_REQUIRE(!tile_stats, "transposed conv: this geometry leaves no tile statistics");
     // one launch per class
     for (int cy = 0; cy < stride; cy++) {
         for (int cx = 0; cx < stride; cx++) {
@@ -568,6 +585,29 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
         }
     }
     return STMI_OK;
+}
+
+// Statistics rows per sample the forward of a transposed convolution x[n,h,w,ci] -> y[n,s*h,s*w,co] can leave
+// (conv_dgrad_impl(..., tile_stats)), 0 when the kernel that runs this geometry leaves none.
+int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (stride < 2 || stride * stride > 4) return 0;
+    // as conv_dgrad_impl sees it: the backward-data of a conv (n, s*h, s*w, co) -> ci
+    const int H = h * stride, W = w * stride;
+    int ho, wo, pt, pl;
+    same_pads(H, kh, stride, &ho, &pt);
+    same_pads(W, kw, stride, &wo, &pl);
+    const PackGeom g = pack_geom(kh, kw, co, ci, STMI_PACK_DGRAD);
+    if (g.row) return 0;
+    ConvGemmParams p;
+    clear_params(p);
+    p.alpha = 1.f;
+    p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = ci;
+    p.Ho = H; p.Wo = W; p.Co = co;
+    p.klen = g.klen; p.kpad = g.kpad; p.co_pad = g.rows_pad;
+    p.in_stride = 1;
+    ConvGemmParams m;
+    if (!build_multi_class(p, H, W, kh, kw, stride, pt, pl, dtype, m)) return 0;
+    return conv_up2_tile_stats_tiles(m, dtype);
 }
 
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,

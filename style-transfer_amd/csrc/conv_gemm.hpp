@@ -413,6 +413,7 @@ bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, 
 
 // Stride-2 backward-data / transposed 3x3 convolution with the input patch resident in LDS (conv_up2.hip), for
 // the multi-class form of the launch (p.nclasses parity classes); false when it does not fit.
+int conv_up2_tile_stats_tiles(const ConvGemmParams& p, int dtype);
 bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
 // Stride-2 backward-data / transposed 3x3 convolution with the input patch resident in LDS (conv_up2.hip), for

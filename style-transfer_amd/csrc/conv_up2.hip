@@ -52,7 +52,13 @@ constexpr int kPatchPieces = (kMaxPatchRows + 31) / 32;   // 8-row pieces per wa
 }  // namespace
 
 // NCH: 128-byte chunks of an input pixel row (Ci * sizeof(T) / 128);  COF: 16-channel fragments of the output
-template <typename T, int NCH, int COF>
+// STATS: the block also leaves the per-tile sums of its output (ConvGemmParams::tile_stats, mode 1: shift, sum,
+// sum of squares, count per channel; ONE row per block) for the instance norm behind a transposed convolution.
+// They are sums of the STORED, rounded tensor (what a separate statistics pass would read), taken from the staged
+// rows: in bf16 with two small MFMAs per fragment (ones^T Y and the diagonal of Y^T Y; plain sums are exact
+// enough for a tensor that itself has eight bits of mantissa, and each wave moves them to a shift before
+// they leave), in fp32 as shifted sums in the lanes that store the rows.
+template <typename T, int NCH, int COF, bool STATS>
 __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;                    // channels per chunk
@@ -195,10 +201,30 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     // One output row at a time goes through the wave's own staging rows ([64 pixels][CO] of T, +16 bytes a
     // row), then out as 16 bytes per lane along whole pixel rows.
     constexpr int SROW = CO * (int)sizeof(T) + 16;        // bytes
+    constexpr int LPR = CO / EPC;                         // lanes per pixel row
+    constexpr bool MSTATS = STATS && sizeof(T) == 2;      // bf16: the sums run on the matrix cores
+    constexpr bool VSTATS = STATS && sizeof(T) == 4;      // fp32: shifted sums in the lanes that store
     __syncthreads();                                      // every wave is done with the patch and the ring
     char* stage = reinterpret_cast<char*>(lds) + wave * (64 * SROW);
     T* out = (T*)p.out;
     const int iy = ty0 + wave;
+    const int lp = lane / LPR, lc = (lane % LPR) * EPC;
+    const int nvalid_px = min(64, p.Wo - 2 * tx0);        // >= 1: the tile exists
+    // VSTATS: statistics of this lane's EPC channels over the pixels it stores; shift: the wave's first pixel
+    float sk[EPC], s1[EPC], s2[EPC], cnt = 0.f;
+#pragma unroll
+    for (int u = 0; u < EPC; u++) sk[u] = s1[u] = s2[u] = 0.f;
+    // MSTATS: for the 16-channel group k, acc_s = ones^T Y (every row: the column sums of the staged rows Y
+    // [64 pixels][CO]) and acc_q = Y^T Y (its diagonal: the sums of squares), K = pixels.  The operand is the
+    // hardware-transposed read of the staging rows; its K order is the same on both sides of a product.
+    f32x4 acc_s[MSTATS ? COF : 1], acc_q[MSTATS ? COF : 1];
+    float k_first[MSTATS ? COF : 1];                      // shift: the wave's first stored pixel, channel 16 k + r16
+#pragma unroll
+    for (int k = 0; k < (MSTATS ? COF : 1); k++) {
+        acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        k_first[k] = 0.f;
+    }
+    int rows_valid = 0;
 #pragma unroll
     for (int cy = 0; cy < 2; cy++) {
         const int oy = 2 * iy + cy;
@@ -215,9 +241,10 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
                 }
         lds_wait();   // the wave's own rows: no barrier
         asm volatile("" ::: "memory");
+        if constexpr (VSTATS) {
+            if (cy == 0) load_vec<T, EPC>(reinterpret_cast<const T*>(stage + lc * (int)sizeof(T)), sk);   // pixel 0 of the row
+        }
         if (oy < p.Ho) {
-            constexpr int LPR = CO / EPC;                 // lanes per pixel row
-            const int lp = lane / LPR, lc = (lane % LPR) * EPC;
             T* orow = out + ((long)(n * p.Ho + oy) * p.Wo) * p.Co;
 #pragma unroll
             for (int i = 0; i < LPR; i++) {
@@ -226,47 +253,168 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
                 if (ox < p.Wo) {
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + px * SROW + lc * (int)sizeof(T));
                     *reinterpret_cast<uint4*>(orow + (long)ox * p.Co + lc) = v;
+                    if constexpr (VSTATS) {
+                        float f[EPC];
+                        unpack_vec<T, EPC>(v, f);
+#pragma unroll
+                        for (int u = 0; u < EPC; u++) {
+                            const float d = f[u] - sk[u];
+                            s1[u] += d;
+                            s2[u] += d * d;
+                        }
+                        cnt += 1.f;
+                    }
                 }
+            }
+            if constexpr (MSTATS) {
+                if (cy == 0) {
+#pragma unroll
+                    for (int k = 0; k < COF; k++) k_first[k] = to_f32<T>(reinterpret_cast<const T*>(stage)[k * 16 + r16]);
+                }
+                // pixels past the right edge were computed but are not part of the tensor: their rows become zeros
+                if (nvalid_px < 64 && lane >= nvalid_px) {
+#pragma unroll
+                    for (int c = 0; c < CO * (int)sizeof(T); c += 16)
+                        *reinterpret_cast<uint4*>(stage + lane * SROW + c) = make_uint4(0u, 0u, 0u, 0u);
+                }
+                asm volatile("" ::: "memory");
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const int q = r16 >> 2, pp = r16 & 3;
+                bf16x8 ones;
+#pragma unroll
+                for (int u = 0; u < 8; u++) ones[u] = (__bf16)1.0f;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int k = 0; k < COF; k++) {
+                        // 16 channels (16 k ..) x 32 pixels (32 h ..): lane (g, q, pp) reads 8 bytes of rows 4 g + q and + 16
+                        const char* a0 = stage + (32 * h + 4 * g + q) * SROW + (2 * k + (pp >> 1)) * 16 + ((pp & 1) << 3);
+                        union {
+                            s16x4 hv[2];
+                            bf16x8 f;
+                        } y;
+                        y.hv[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+                        y.hv[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * SROW));
+                        acc_s[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, y.f, acc_s[k], 0, 0, 0);
+                        acc_q[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y.f, y.f, acc_q[k], 0, 0, 0);
+                    }
+                rows_valid++;
             }
         }
         lds_wait();
         asm volatile("" ::: "memory");
+    }
+    if constexpr (STATS) {
+        float* part = reinterpret_cast<float*>(lds);      // [wave][plane k, s1, s2, count][CO]
+        if constexpr (VSTATS) {
+            // lanes of one channel group (lane % LPR) -> the wave's sums
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+                for (int u = 0; u < EPC; u++) {
+                    s1[u] += __shfl_xor(s1[u], off);
+                    s2[u] += __shfl_xor(s2[u], off);
+                }
+                cnt += __shfl_xor(cnt, off);
+            }
+        }
+        lds_barrier();                                    // every wave is done with its staging rows
+        if constexpr (VSTATS) {
+            if (lane < LPR) {
+#pragma unroll
+                for (int u = 0; u < EPC; u++) {
+                    float* e = part + wave * 4 * CO + lc + u;
+                    e[0] = sk[u];
+                    e[CO] = s1[u];
+                    e[2 * CO] = s2[u];
+                    e[3 * CO] = cnt;
+                }
+            }
+        } else {
+            // C/D layout: lane (g, r16), register u = row 4 g + u, column r16.  Column sums: any row; squares:
+            // the diagonal, row = column.  The lanes with g == r16 / 4 hold both for channel 16 k + r16; they
+            // move the plain sums to the shift (this wave's first pixel) so that the rows combine without
+            // cancellation: sum(y - k) = S - n k, sum((y - k)^2) = Q - 2 k S + n k^2.
+            if (g == (r16 >> 2)) {
+                const float nw = (float)(rows_valid * nvalid_px);
+#pragma unroll
+                for (int k = 0; k < COF; k++) {
+                    const float S = acc_s[k][r16 & 3], Q = acc_q[k][r16 & 3], kf = k_first[k];
+                    float* e = part + wave * 4 * CO + k * 16 + r16;
+                    e[0] = kf;
+                    e[CO] = S - nw * kf;
+                    e[2 * CO] = fmaxf(Q - 2.f * kf * S + nw * kf * kf, 0.f);
+                    e[3 * CO] = nw;
+                }
+            }
+        }
+        lds_barrier();
+        // waves -> the block's row, moved to wave 0's shift (its first pixel is always inside the image):
+        // sum(x - k0) = s1 + n d, sum((x - k0)^2) = s2 + 2 d s1 + n d^2,  d = k_w - k0
+        if (tid < CO && tid < p.Co) {
+            const float k0 = part[tid];
+            float t1 = 0.f, t2 = 0.f, tc = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < 4; w_++) {
+                const float* e = part + w_ * 4 * CO + tid;
+                const float c_ = e[3 * CO];
+                if (c_ > 0.f) {
+                    const float d = e[0] - k0;
+                    t1 += e[CO] + c_ * d;
+                    t2 += e[2 * CO] + 2.f * d * e[CO] + c_ * d * d;
+                    tc += c_;
+                }
+            }
+            const unsigned tile_in_sample = tile - (unsigned)n * tiles_x * tiles_y;
+            float* row = p.tile_stats + (((long)n * p.tile_stats_ts + tile_in_sample) * 4) * p.Co + tid;
+            row[0] = k0;
+            row[p.Co] = t1;
+            row[2 * p.Co] = t2;
+            row[3 * p.Co] = tc;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename T, int NCH, int COF>
+template <typename T, int NCH, int COF, bool STATS>
 static int launch_up2(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kOperands = (size_t)kRing * 16 * COF * 128 + (size_t)NCH * 4 * kPatchPieces * 1024;
     constexpr size_t kStage = (size_t)4 * 64 * (16 * COF * sizeof(T) + 16);
     constexpr size_t kLds = kOperands > kStage ? kOperands : kStage;
     static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
     if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_up2_kernel<T, NCH, COF>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_up2_kernel<T, NCH, COF, STATS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_up2_kernel)");
         if (rc) return rc;
         attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv_up2_kernel<T, NCH, COF>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
+    hipLaunchKernelGGL((conv_up2_kernel<T, NCH, COF, STATS>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
     STMI_LAUNCH_CHECK("conv_up2_kernel");
     return STMI_OK;
 }
 
+template <typename T, int NCH, int COF>
+static int launch_up2_s(const ConvGemmParams& p, hipStream_t s) {
+    return p.tile_stats ? launch_up2<T, NCH, COF, true>(p, s) : launch_up2<T, NCH, COF, false>(p, s);
+}
+
 // p: the multi-class form of a stride-2 backward-data launch (nclasses sub-grids with oys = oxs = 2, in_stride 1).
-bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
+// Fills q, the launch form of p (halo and grid in the pt_ fields); false: the layer is not one of this kernel's.
+static bool up2_prepare(const ConvGemmParams& p, int dtype, ConvGemmParams& q) {
     if (STMI_ENV_SET("STMI_NO_UP2")) return false;
     const int es = dtype == STMI_BF16 ? 2 : 4;
     if (p.nclasses < 1 || p.nclasses > 4 || p.oys != 2 || p.oxs != 2 || p.in_stride != 1 || p.cdiv != 0) return false;
     if (p.klen != p.Ci || (p.Ci * es) % 128 != 0 || (p.Co != 32 && p.Co != 64) || p.co_pad < p.Co) return false;
     const int nch = p.Ci * es / 128;
     if (nch != 1 && nch != 2 && nch != 4) return false;
-    if (p.bias || p.mask || p.addend || p.out_pre || p.relu || p.tile_stats || p.w_batch_stride != 0) return false;
+    if (p.bias || p.mask || p.addend || p.out_pre || p.relu || p.w_batch_stride != 0) return false;
+    if (p.tile_stats && p.tile_stats_mode != 1) return false;
     if ((((uintptr_t)p.in | (uintptr_t)p.wp | (uintptr_t)p.out) & 15) != 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
-    ConvGemmParams q = p;
+    q = p;
     int dy_min = 0, dy_max = 0, dx_min = 0, dx_max = 0, hs = 0, ws = 0, nt = 0;
     ConvGemmParams::SubGrid slots[4] = {};
     for (int c = 0; c < p.nclasses; c++) {
@@ -302,18 +450,34 @@ bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int*
     q.pt_magic[1] = (unsigned)(dx_min + 1);
     q.pt_magic[2] = (unsigned)(dx_max - dx_min);
     if ((long)q.pt_div[1] * q.pt_div[2] * p.N >= (1L << 31)) return false;
+    return true;
+}
+
+// Statistics rows per sample this kernel leaves for the launch p (one per block), 0 when p is not its layer.
+int conv_up2_tile_stats_tiles(const ConvGemmParams& p, int dtype) {
+    ConvGemmParams q;
+    if (!up2_prepare(p, dtype, q)) return 0;
+    return (int)(q.pt_div[1] * q.pt_div[2]);
+}
+
+bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
+    ConvGemmParams q;
+    if (!up2_prepare(p, dtype, q)) return false;
+    if (p.tile_stats && p.tile_stats_ts != (int)(q.pt_div[1] * q.pt_div[2])) return false;
+    const int es = dtype == STMI_BF16 ? 2 : 4;
+    const int nch = p.Ci * es / 128;
     const int cof = p.Co / 16;
     if (name)
-        snprintf(name, name_len, "void stmi::conv_up2_kernel<%s, %d, %d>(stmi::ConvGemmParams)",
-                 dtype == STMI_BF16 ? "__bf16" : "float", nch, cof);
+        snprintf(name, name_len, "void stmi::conv_up2_kernel<%s, %d, %d, %s>(stmi::ConvGemmParams)",
+                 dtype == STMI_BF16 ? "__bf16" : "float", nch, cof, p.tile_stats ? "true" : "false");
     if (dtype == STMI_BF16) {
-        if (nch == 1) *rc = cof == 2 ? launch_up2<bf16_t, 1, 2>(q, s) : launch_up2<bf16_t, 1, 4>(q, s);
-        else if (nch == 2) *rc = cof == 2 ? launch_up2<bf16_t, 2, 2>(q, s) : launch_up2<bf16_t, 2, 4>(q, s);
-        else *rc = cof == 2 ? launch_up2<bf16_t, 4, 2>(q, s) : launch_up2<bf16_t, 4, 4>(q, s);
+        if (nch == 1) *rc = cof == 2 ? launch_up2_s<bf16_t, 1, 2>(q, s) : launch_up2_s<bf16_t, 1, 4>(q, s);
+        else if (nch == 2) *rc = cof == 2 ? launch_up2_s<bf16_t, 2, 2>(q, s) : launch_up2_s<bf16_t, 2, 4>(q, s);
+        else *rc = cof == 2 ? launch_up2_s<bf16_t, 4, 2>(q, s) : launch_up2_s<bf16_t, 4, 4>(q, s);
     } else {
-        if (nch == 1) *rc = cof == 2 ? launch_up2<float, 1, 2>(q, s) : launch_up2<float, 1, 4>(q, s);
-        else if (nch == 2) *rc = cof == 2 ? launch_up2<float, 2, 2>(q, s) : launch_up2<float, 2, 4>(q, s);
-        else *rc = cof == 2 ? launch_up2<float, 4, 2>(q, s) : launch_up2<float, 4, 4>(q, s);
+        if (nch == 1) *rc = cof == 2 ? launch_up2_s<float, 1, 2>(q, s) : launch_up2_s<float, 1, 4>(q, s);
+        else if (nch == 2) *rc = cof == 2 ? launch_up2_s<float, 2, 2>(q, s) : launch_up2_s<float, 2, 4>(q, s);
+        else *rc = cof == 2 ? launch_up2_s<float, 4, 2>(q, s) : launch_up2_s<float, 4, 4>(q, s);
     }
     return true;
 }

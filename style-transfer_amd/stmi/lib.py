@@ -39,6 +39,8 @@ SIGNATURES = {
     'stmi_conv2d_nhwc_dgrad_in_sums': (_c_int, [_vp] * 5 + [_c_float] + [_vp] * 4 + [_c_int, _vp] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_fwd': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
+    'stmi_conv2d_transpose_tile_stats_tiles': (_c_int, _CONV + [_c_int]),
+    'stmi_conv2d_transpose_nhwc_fwd_tile_stats': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_dgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_instance_norm_ws_floats': (_c_long, [_c_int] * 4),

@@ -259,9 +259,18 @@ def conv2d_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
     return dw
 
 
-def conv2d_transpose_fwd(x, w_packed, kshape, stride, out=None):
+def conv_transpose_tile_stats_tiles(x_shape, kshape, stride, dtype):
+    """Statistics rows per sample conv2d_transpose_fwd(tile_stats=...) leaves for this geometry (0: none)."""
+    kh, kw, co, ci = kshape
+    n, h, w, _ = x_shape
+    return int(_lib.load().stmi_conv2d_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
+def conv2d_transpose_fwd(x, w_packed, kshape, stride, out=None, tile_stats=None):
     """kshape = (kh, kw, co, ci) of the reference's transposed-conv weight; packed with
-    PACK_DGRAD as if it were the HWIO weight of a conv co -> ci."""
+    PACK_DGRAD as if it were the HWIO weight of a conv co -> ci.
+    tile_stats: fp32 [n, conv_transpose_tile_stats_tiles(...), 4, co] that receives the per-tile sums of y for
+    instance_norm_fwd(tile_stats=...)."""
     kh, kw, co, ci = kshape
     n, h, w, c = x.shape
     assert c == ci
@@ -269,6 +278,12 @@ def conv2d_transpose_fwd(x, w_packed, kshape, stride, out=None):
     _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, co, ci, PACK_DGRAD),))
     oshape = (n, h * stride, w * stride, co)
     y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    if tile_stats is not None:
+        _chk(tile_stats, 'tile_stats', torch.float32,
+             (n, conv_transpose_tile_stats_tiles(x.shape, kshape, stride, x.dtype), 4, co))
+        _lib.call('stmi_conv2d_transpose_nhwc_fwd_tile_stats', x.data_ptr(), w_packed.data_ptr(), y.data_ptr(),
+                  tile_stats.data_ptr(), n, h, w, ci, co, kh, kw, stride, _dt(x), _stream())
+        return y
     _lib.call('stmi_conv2d_transpose_nhwc_fwd', x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), n, h, w, ci, co,
               kh, kw, stride, _dt(x), _stream())
     return y

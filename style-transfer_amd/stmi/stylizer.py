@@ -134,6 +134,12 @@ class StylizerNet:
                 if 0 < ts <= int(os.environ.get('STMI_TILE_STATS_MAX', '32')) or (
                         ts > 0 and ops.conv_tile_stats_free((batch, h, w, c), b.kshape, s, dtype)):
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
+            # ... transposed convolutions: the up-sampling kernel takes the sums from the rows it stores
+            # (STMI_TILE_STATS_UP=0: tuning aid, off)
+            if kind == 'deconv' and os.environ.get('STMI_TILE_STATS', '1') == '1' and os.environ.get('STMI_TILE_STATS_UP', '1') == '1':
+                ts = ops.conv_transpose_tile_stats_tiles((batch, h, w, c), b.kshape, s, dtype)
+                if ts > 0:
+                    b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... and in the backward pass the data-gradient kernel of this block can leave the sums the
             # instance norm of the block BELOW needs (its output gradient is what the kernel writes), so
             # that norm's backward skips its reduction pass (STMI_IN_SUMS=0: off)
@@ -237,7 +243,7 @@ class StylizerNet:
                         (cur.data_ptr(), None if skip is None else skip.data_ptr())]
                 conv_out, y = self._view(free[0], b), self._view(free[1], b)
             if b.kind == 'deconv':
-                ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out)
+                ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             elif b.rgb:
                 ops.conv2d_rgb_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out)
             elif b.rows == 'in':

@@ -253,6 +253,43 @@ def test_conv_transpose(cuda, dtype, case):
     assert rel_err(dw, gw_ref) <= TOL[dtype]
 
 
+UP_STAT_CASES = [(2, 6, 5, 128, 64), (1, 7, 40, 64, 32), (3, 9, 70, 128, 64), (1, 1, 1, 64, 32), (1, 135, 130, 64, 32)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', UP_STAT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_transpose_tile_statistics_feed_instance_norm(cuda, dtype, case):
+    """conv2d_transpose_fwd(tile_stats=) + instance_norm_fwd(tile_stats=): same output as the plain launch; the
+    sums are those of the STORED tensor, so the statistics equal the separate statistics pass over it (to fp32
+    summation order) and the normalized result meets the oracle.  Ragged 4 x 32 input tiles, one-pixel input,
+    more rows than the apply blocks fold."""
+    from stmi import ops
+    n, h, w, ci, co = case
+    k, s = 3, 2
+    x = rnd((n, h, w, ci), 1) * 0.5 + 0.8
+    wt = rnd((k, k, co, ci), 2, 1.0 / np.sqrt(k * k * ci))
+    wt[1, 1] += 0.05           # non-zero-mean output
+    scale, shift = rnd((co,), 3) + 1.5, rnd((co,), 4)
+    xd = x.to(cuda, dtype)
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    ts = ops.conv_transpose_tile_stats_tiles(xd.shape, (k, k, co, ci), s, dtype)
+    assert ts == -(-h // 4) * -(-w // 32), 'this geometry runs on the up-sampling kernel'
+    tiles = torch.full((n, ts, 4, co), float('nan'), dtype=torch.float32, device=cuda)
+    y = ops.conv2d_transpose_fwd(xd, wp, (k, k, co, ci), s, tile_stats=tiles)
+    assert torch.equal(y, ops.conv2d_transpose_fwd(xd, wp, (k, k, co, ci), s)), 'the statistics must not change the output'
+    assert bool(torch.isfinite(tiles).all())
+    assert tiles[:, :, 3].sum(dim=1).eq(4 * h * w).all(), 'tile pixel counts add up to the plane'
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    y_a, st_a = ops.instance_norm_fwd(y, sd, hd, ops.ACT_RELU, tile_stats=tiles)
+    y_b, st_b = ops.instance_norm_fwd(y, sd, hd, ops.ACT_RELU)
+    assert rel_err(st_a[..., 0], st_b[..., 0]) <= 1e-5
+    assert rel_err(st_a[..., 1], st_b[..., 1]) <= 1e-4
+    y_ref = O.conv2d_transpose_same(q(x, dtype), q(wt, dtype), s)
+    ref = torch.relu(O.instance_norm(y_ref, scale.float().double(), shift.float().double()))
+    assert rel_err(y_a, ref) <= TOL[dtype]
+    assert rel_err(y_b, ref) <= TOL[dtype]
+
+
 PERS_CASES = [(3, 130, 250, 128, 64), (3, 126, 260, 128, 128), (2, 254, 250, 64, 64)]   # three block rounds and more
 
 

@@ -132,10 +132,18 @@ def test_training_step_fp32(cuda, use_graph):
     v = [torch.zeros_like(p) for p in P]
     for t in range(2):
         O.adam_tf1_step(P, own_grads[t], m, v, t + 1)
+    # ... so the direction is taken over the elements whose oracle gradient is well above the gradient
+    # tolerance in both steps (elsewhere its sign is not determined at 2e-3 of the tensor's maximum, and the
+    # float atomics of the weight-gradient kernels decide it differently from run to run).
     for i, (p, mine, r, p0) in enumerate(zip(tr.net.views, P, ref_params, params)):
         assert rel_err(p, mine) <= 1e-5, 'Adam on own gradients, variable %d' % i
         p0 = torch.tensor(p0, dtype=torch.float64)
-        du, dr = (p.double().cpu() - p0).reshape(-1), (r - p0).reshape(-1)
+        keep = torch.ones_like(p0, dtype=torch.bool)
+        for t in range(2):
+            g = ref[t][2][i]
+            keep &= g.abs() >= 2e-2 * g.abs().max()
+        assert keep.float().mean().item() >= 0.5, 'variable %d: too few well-determined elements' % i
+        du, dr = (p.double().cpu() - p0)[keep], (r - p0)[keep]
         assert (du @ dr / (du.norm() * dr.norm())).item() >= 0.999, 'update direction of variable %d' % i
 
 
