@@ -118,6 +118,16 @@ int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean,
                              const float* bias, void* y, void* y_pre,
                              int n, int h, int w, int co, int k, int relu, int dtype, void* stream);
 
+/* stmi_conv2d_rgb_nhwc_fwd (no bias, no ReLU) that also leaves the per-tile sums of y described at
+ * stmi_conv2d_tile_stats_tiles for the instance norm that follows the stylizer's first layer
+ * (model_utilities.py:235-242: conv, then instance_norm).  stmi_conv2d_rgb_tile_stats_tiles: rows per sample
+ * (one per 8 x 32 block of output pixels; 0: none for this (k, co) - built for (9, 32)); tile_stats holds
+ * n * tiles * 4 * co floats. */
+int stmi_conv2d_rgb_tile_stats_tiles(int h, int w, int co, int k);
+int stmi_conv2d_rgb_nhwc_fwd_tile_stats(const float* x_f32, float scale, const float* mean, const void* w_packed_rgb,
+                                        void* y, float* tile_stats,
+                                        int n, int h, int w, int co, int k, int dtype, void* stream);
+
 /* k x k stride-1 SAME convolution ci -> 3 in one launch (the stylizer's last layer,
  * full_graph_stylizer_network.py:78; with the flipped, transposed kernel it is the backward-data of VGG
  * conv1_1): x [n,h,w,ci] -> y [n,h,w,3] = conv(x) + addend (optional, shaped like y).  W packed with

@@ -41,7 +41,9 @@ int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const fl
                      float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
                      int dtype, hipStream_t s);
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
-                      void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s);
+                      void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s,
+                      float* tile_stats = nullptr);
+int conv_rgb_tile_stats_tiles(int h, int w, int co, int k);
 int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
                         hipStream_t s);
 int conv_to3_supported(int k, int ci, int dtype);
@@ -199,6 +201,23 @@ int stmi_conv2d_rgb_nhwc_fwd(const float* x_f32, float scale, const float* mean,
     if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x_f32 && w_packed_rgb && y, "conv2d_rgb_nhwc_fwd: null pointer");
     return conv_rgb_fwd_impl(x_f32, scale, mean, w_packed_rgb, bias, y, y_pre, n, h, w, co, k, relu, dtype, S(stream));
+}
+
+int stmi_conv2d_rgb_tile_stats_tiles(int h, int w, int co, int k) {
+    if (h <= 0 || w <= 0 || co <= 0 || k <= 0) return 0;
+    return conv_rgb_tile_stats_tiles(h, w, co, k);
+}
+
+int stmi_conv2d_rgb_nhwc_fwd_tile_stats(const float* x_f32, float scale, const float* mean, const void* w_packed_rgb,
+                                        void* y, float* tile_stats, int n, int h, int w, int co, int k, int dtype,
+                                        void* stream) {
+    if (check_conv("conv2d_rgb_nhwc_fwd_tile_stats", n, h, w, 3, co, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
+    STMI_REQUIRE(x_f32 && w_packed_rgb && y && tile_stats, "conv2d_rgb_nhwc_fwd_tile_stats: null pointer");
+    STMI_REQUIRE(conv_rgb_tile_stats_tiles(h, w, co, k) > 0, "conv2d_rgb_nhwc_fwd_tile_stats: no tile statistics "
+                 "for this (k, co) (stmi_conv2d_rgb_tile_stats_tiles returned 0)");
+    return conv_rgb_fwd_impl(x_f32, scale, mean, w_packed_rgb, nullptr, y, nullptr, n, h, w, co, k, 0, dtype, S(stream),
+                             tile_stats);
 }
 
 int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, void* dx, int n, int h, int w, int ci,

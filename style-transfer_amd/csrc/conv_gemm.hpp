@@ -386,6 +386,134 @@ __device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, co
     conv_epilogue<T, TC, TP>(p, acc, co0, pix0, wave / WP, wave % WP, lane >> 4, lane & 15, Mz, zoff, HWs);
 }
 
+// ---------------------------------------------------------------------------
+// Tile statistics (ConvGemmParams::tile_stats, mode 1) for kernels whose waves stage their output as
+// [64 pixels][CO] rows of T in LDS (row stride SROW bytes, a multiple of 16) before storing whole rows: sums
+// of the STORED, rounded tensor -- what a separate statistics pass over it would read.
+//   bf16: for every 16-channel group, ones^T Y (column sums of the staged rows Y) and the diagonal of Y^T Y (sums
+//         of squares) on the matrix cores, K = pixels; the operand is the hardware-transposed read of the rows,
+//         whose K order is the same on both sides of a product.  Plain sums are exact enough for a tensor that
+//         itself has eight bits of mantissa; each wave moves them to a shift before they leave.  Rows of pixels
+//         outside the tensor must hold zeros.
+//   fp32: shifted sums in the lanes that store the rows (WaveStatsLanes).
+// The four waves' partial rows meet in LDS (`part`: 4 x 4 x CO floats) and leave as ONE row per block.
+// ---------------------------------------------------------------------------
+template <int CO>
+__device__ __forceinline__ void wave_stats_mma(const char* stage, int srow, int lane, f32x4 (&acc_s)[CO / 16],
+                                               f32x4 (&acc_q)[CO / 16]) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int g = lane >> 4, r16 = lane & 15, q = r16 >> 2, pp = r16 & 3;
+    bf16x8 ones;
+#pragma unroll
+    for (int u = 0; u < 8; u++) ones[u] = (__bf16)1.0f;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < CO / 16; k++) {
+            // 16 channels (16 k ..) x 32 pixels (32 h ..): lane (g, q, pp) reads 8 bytes of rows 4 g + q and + 16
+            const char* a0 = stage + (32 * h + 4 * g + q) * srow + (2 * k + (pp >> 1)) * 16 + ((pp & 1) << 3);
+            union {
+                s16x4 hv[2];
+                bf16x8 f;
+            } y;
+            y.hv[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+            y.hv[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * srow));
+            acc_s[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, y.f, acc_s[k], 0, 0, 0);
+            acc_q[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y.f, y.f, acc_q[k], 0, 0, 0);
+        }
+}
+
+// The wave's row of `part` from the MFMA sums.  C/D layout: lane (g, r16), register u = row 4 g + u, column r16;
+// column sums sit in any row, squares on the diagonal: the lanes with g == r16 / 4 hold both for channel
+// 16 k + r16.  k_first: the shift (a stored pixel of the wave), nw: pixels summed.
+//   sum(y - k) = S - n k,  sum((y - k)^2) = Q - 2 k S + n k^2
+template <int CO>
+__device__ __forceinline__ void wave_stats_part_mma(float* part_wave, int lane, const f32x4 (&acc_s)[CO / 16],
+                                                    const f32x4 (&acc_q)[CO / 16], const float (&k_first)[CO / 16], float nw) {
+    const int g = lane >> 4, r16 = lane & 15;
+    if (g != (r16 >> 2)) return;
+#pragma unroll
+    for (int k = 0; k < CO / 16; k++) {
+        const float S = acc_s[k][r16 & 3], Q = acc_q[k][r16 & 3], kf = k_first[k];
+        float* e = part_wave + k * 16 + r16;
+        e[0] = kf;
+        e[CO] = S - nw * kf;
+        e[2 * CO] = fmaxf(Q - 2.f * kf * S + nw * kf * kf, 0.f);
+        e[3 * CO] = nw;
+    }
+}
+
+// fp32 form: a lane stores EPC channels (lc ..) of some of the wave's pixels and sums them as it goes.
+template <typename T, int CO>
+struct WaveStatsLanes {
+    static constexpr int EPC = 16 / (int)sizeof(T), LPR = CO / EPC;
+    float sk[EPC], s1[EPC], s2[EPC], cnt;
+    __device__ __forceinline__ void init() {
+        cnt = 0.f;
+#pragma unroll
+        for (int u = 0; u < EPC; u++) sk[u] = s1[u] = s2[u] = 0.f;
+    }
+    __device__ __forceinline__ void add(const uint4& v) {
+        float f[EPC];
+        unpack_vec<T, EPC>(v, f);
+#pragma unroll
+        for (int u = 0; u < EPC; u++) {
+            const float d = f[u] - sk[u];
+            s1[u] += d;
+            s2[u] += d * d;
+        }
+        cnt += 1.f;
+    }
+    // lanes of one channel group (lane % LPR) -> the wave's sums -> its row of `part`
+    __device__ __forceinline__ void reduce() {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+            for (int u = 0; u < EPC; u++) {
+                s1[u] += __shfl_xor(s1[u], off);
+                s2[u] += __shfl_xor(s2[u], off);
+            }
+            cnt += __shfl_xor(cnt, off);
+        }
+    }
+    __device__ __forceinline__ void write_part(float* part_wave, int lane) const {
+        if (lane >= LPR) return;
+#pragma unroll
+        for (int u = 0; u < EPC; u++) {
+            float* e = part_wave + lane * EPC + u;
+            e[0] = sk[u];
+            e[CO] = s1[u];
+            e[2 * CO] = s2[u];
+            e[3 * CO] = cnt;
+        }
+    }
+};
+
+// Waves -> the block's statistics row, moved to wave 0's shift (its first pixel must be inside the tensor):
+// sum(x - k0) = s1 + n d, sum((x - k0)^2) = s2 + 2 d s1 + n d^2,  d = k_w - k0.  Threads 0 .. CO - 1; row: the
+// block's row of the tile_stats tensor (planes C apart).
+template <int CO>
+__device__ __forceinline__ void block_stats_row(const float* part, int tid, float* row, int C) {
+    if (tid >= CO || tid >= C) return;
+    const float k0 = part[tid];
+    float t1 = 0.f, t2 = 0.f, tc = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; w_++) {
+        const float* e = part + w_ * 4 * CO + tid;
+        const float c_ = e[3 * CO];
+        if (c_ > 0.f) {
+            const float d = e[0] - k0;
+            t1 += e[CO] + c_ * d;
+            t2 += e[2 * CO] + 2.f * d * e[CO] + c_ * d * d;
+            tc += c_;
+        }
+    }
+    row[tid] = k0;
+    row[C + tid] = t1;
+    row[2 * C + tid] = t2;
+    row[3 * C + tid] = tc;
+}
+
 // Optional extra of a backward-data convolution: per-tile sums for the backward pass of the instance norm
 // whose OUTPUT gradient the convolution writes (ConvGemmParams::tile_stats, mode 2).
 struct InBwdSums {

@@ -25,7 +25,11 @@ constexpr int kRgbPH = 8, kRgbPW = 32;  // output pixels per block: 4 waves x (2
 
 // XT: element type of the image, float (forward layers) or T (backward-data of a layer that WRITES 3
 // channels: its input gradient is this same convolution of dy with the flipped, transposed kernel).
-template <typename T, int K, int TC, typename XT>
+// STATS: the block also leaves the per-tile sums of its output (ConvGemmParams::tile_stats, mode 1; one row per
+// block) for the instance norm behind the stylizer's first layer.  That form has its own epilogue: a wave
+// stages its 2 x 32 pixels as [64][CO] rows of T, stores them as whole rows and takes the sums from the staged
+// rows (conv_gemm.hpp, wave_stats_mma / WaveStatsLanes); no bias, ReLU or pre-activation copy.
+template <typename T, int K, int TC, typename XT, bool STATS>
 __global__ __launch_bounds__(256) void conv_rgb_kernel(const XT* __restrict__ x, float scale, const float* mean,
                                                        const T* __restrict__ wq, const ConvGemmParams p) {
     constexpr int EPC = 16 / (int)sizeof(T);     // elements per 16-byte K fragment
@@ -118,6 +122,69 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const XT* __restrict__ x,
             for (int tp = 0; tp < TP; tp++) Mma<T>::mma(a[tc], b[tp], acc[tc][tp]);
     }
 
+    if constexpr (STATS) {
+        constexpr int SROW = CO * (int)sizeof(T) + 16;    // bytes
+        constexpr int LPR = CO / EPC;                     // lanes per pixel row
+        __syncthreads();                                  // every wave is done with the weights and the patch
+        char* stage = lds + wave * (64 * SROW);
+        // staged row px of the wave = tile pixel (2 wave + px / 32, px % 32); fragment tp covers px 16 tp ..
+#pragma unroll
+        for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+            for (int tp = 0; tp < TP; tp++) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = acc[tc][tp][u];
+                store_vec<T, 4>(reinterpret_cast<T*>(stage + (tp * 16 + r16) * SROW) + tc * 16 + 4 * g, v);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own rows: no barrier
+        const int oy0 = ty0 + 2 * wave;
+        const int rows_valid = max(0, min(2, H - oy0)), px_valid = min(PW, W - tx0);
+        const int lp = lane / LPR, lc = (lane % LPR) * EPC;
+        WaveStatsLanes<T, CO> vs;
+        vs.init();
+        if constexpr (sizeof(T) == 4) load_vec<T, EPC>(reinterpret_cast<const T*>(stage + lc * (int)sizeof(T)), vs.sk);
+        T* out = (T*)p.out;
+#pragma unroll
+        for (int i = 0; i < LPR; i++) {
+            const int px = lp + i * (64 / LPR);
+            const int oy = oy0 + (px >> 5), ox = tx0 + (px & 31);
+            if (oy < H && ox < W) {
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + px * SROW + lc * (int)sizeof(T));
+                *reinterpret_cast<uint4*>(out + (((long)n * H + oy) * W + ox) * p.Co + lc) = v;
+                if constexpr (sizeof(T) == 4) vs.add(v);
+            }
+        }
+        float* part = reinterpret_cast<float*>(lds);      // [wave][plane k, s1, s2, count][CO]
+        f32x4 acc_s[TC], acc_q[TC];
+        float k_first[TC];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                k_first[k] = to_f32<T>(reinterpret_cast<const T*>(stage)[k * 16 + r16]);
+            }
+            // pixels outside the image were computed but are not part of the tensor: their rows become zeros
+            if (rows_valid * px_valid < 64 && ((lane >> 5) >= rows_valid || (lane & 31) >= px_valid)) {
+#pragma unroll
+                for (int c = 0; c < CO * (int)sizeof(T); c += 16)
+                    *reinterpret_cast<uint4*>(stage + lane * SROW + c) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            asm volatile("" ::: "memory");
+            if (rows_valid > 0) wave_stats_mma<CO>(stage, SROW, lane, acc_s, acc_q);
+        } else {
+            vs.reduce();
+        }
+        lds_barrier();                                    // every wave is done with its staging rows
+        if constexpr (sizeof(T) == 2)
+            wave_stats_part_mma<CO>(part + wave * 4 * CO, lane, acc_s, acc_q, k_first, (float)(rows_valid * px_valid));
+        else
+            vs.write_part(part + wave * 4 * CO, lane);
+        lds_barrier();
+        // wave 0's first pixel (ty0, tx0) is always inside the image
+        block_stats_row<CO>(part, tid, p.tile_stats + (((long)n * (tiles_x * tiles_y) + t) * 4) * p.Co, p.Co);
+        return;
+    }
     constexpr int TPG = conv_stage_tpg(TC, TP, 1, 4, 160 * 1024 / 2);
     static_assert(TPG >= 1, "staging area");
     const long img_row = (long)n * H;
@@ -133,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const XT* __restrict__ x,
 // ---------------------------------------------------------------------------
 int conv_rgb_klen(int k) { return (4 * k * (k + 1) + 31) / 32 * 32; }
 
-template <typename T, int K, int TC, typename XT>
+template <typename T, int K, int TC, typename XT, bool STATS = false>
 static int launch_rgb(const XT* x, float scale, const float* mean, const void* wq, const ConvGemmParams& p,
                       hipStream_t s) {
     constexpr int KL = (4 * K * (K + 1) + 31) / 32 * 32;
@@ -142,10 +209,12 @@ static int launch_rgb(const XT* x, float scale, const float* mean, const void* w
     constexpr int P_BYTES = (kRgbPH + K - 1) * (kRgbPW + K) * 4 * (int)sizeof(T);
     constexpr int TPG = conv_stage_tpg(TC, 4, 1, 4, 160 * 1024 / 2);
     constexpr int S_BYTES = 16 * TPG * 4 * (CO + 4) * 4;
-    constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_BYTES ? W_BYTES + P_BYTES : S_BYTES) + 15) / 16 * 16;
+    constexpr int S_WAVES = 4 * 64 * (CO * (int)sizeof(T) + 16);   // the STATS epilogue's per-wave rows
+    constexpr int S_NEED = STATS ? S_WAVES : S_BYTES;
+    constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_NEED ? W_BYTES + P_BYTES : S_NEED) + 15) / 16 * 16;
     static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
     if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC, XT>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC, XT, STATS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_rgb_kernel)");
         if (rc) return rc;
@@ -155,23 +224,32 @@ static int launch_rgb(const XT* x, float scale, const float* mean, const void* w
         char name[160];
         const char* tn = sizeof(T) == 2 ? "__bf16" : "float";
         const char* xn = sizeof(XT) == 2 ? "__bf16" : "float";
-        snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d, %s>(%s const*, float, float const*, %s const*, stmi::ConvGemmParams)",
-                 tn, K, TC, xn, xn, tn);
+        snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d, %s, %s>(%s const*, float, float const*, %s const*, stmi::ConvGemmParams)",
+                 tn, K, TC, xn, STATS ? "true" : "false", xn, tn);
         set_last_conv_kernel(name);
     }
     const long tiles = (long)p.N * ceil_div(p.Hi, kRgbPH) * ceil_div(p.Wi, kRgbPW);
     if (tiles <= 0) return STMI_OK;
     STMI_REQUIRE(tiles < (1L << 31), "conv_rgb: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_rgb_kernel<T, K, TC, XT>), dim3((unsigned)tiles), dim3(256), kLds, s, x, scale, mean, (const T*)wq, p);
+    hipLaunchKernelGGL((conv_rgb_kernel<T, K, TC, XT, STATS>), dim3((unsigned)tiles), dim3(256), kLds, s, x, scale, mean, (const T*)wq, p);
     STMI_LAUNCH_CHECK("conv_rgb_kernel");
     return STMI_OK;
 }
 
+// Statistics rows per sample conv_rgb_fwd_impl(..., tile_stats) leaves for (h, w) planes: one per 8 x 32 block of
+// output pixels (0: this configuration has none).
+int conv_rgb_tile_stats_tiles(int h, int w, int co, int k) {
+    if (!(k == 9 && co == 32)) return 0;
+    return ceil_div(h, kRgbPH) * ceil_div(w, kRgbPW);
+}
+
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
-                      void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s) {
+                      void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s,
+                      float* tile_stats) {
     ConvGemmParams p;
     memset(&p, 0, sizeof(p));
     p.out = y; p.out_pre = y_pre; p.bias = bias; p.alpha = 1.f; p.relu = relu;
+    p.tile_stats = tile_stats; p.tile_stats_mode = tile_stats ? 1 : 0;
     p.N = n; p.Hi = h; p.Wi = w; p.Ci = 3;
     p.Ho = h; p.Wo = w; p.Co = co;
     const uintptr_t ptrs = (uintptr_t)y | (uintptr_t)y_pre | (uintptr_t)wq;
@@ -179,6 +257,10 @@ int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void
     STMI_REQUIRE((long)n * h * w * 3 < (1L << 31), "conv_rgb: image batch too large for 32-bit indexing");
     p.row_store_ok = 1;
     const bool bf = dtype == STMI_BF16;
+    if (tile_stats) {
+        STMI_REQUIRE(k == 9 && co == 32 && !bias && !relu && !y_pre, "conv_rgb: tile statistics are built for the plain (9, 32) layer");
+        return bf ? launch_rgb<bf16_t, 9, 2, float, true>(x, scale, mean, wq, p, s) : launch_rgb<float, 9, 2, float, true>(x, scale, mean, wq, p, s);
+    }
     if (k == 9 && co == 32) return bf ? launch_rgb<bf16_t, 9, 2, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 9, 2, float>(x, scale, mean, wq, p, s);
     if (k == 3 && co == 64) return bf ? launch_rgb<bf16_t, 3, 4, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 4, float>(x, scale, mean, wq, p, s);
     if (k == 3 && co == 32) return bf ? launch_rgb<bf16_t, 3, 2, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 2, float>(x, scale, mean, wq, p, s);

@@ -210,17 +210,12 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     const int iy = ty0 + wave;
     const int lp = lane / LPR, lc = (lane % LPR) * EPC;
     const int nvalid_px = min(64, p.Wo - 2 * tx0);        // >= 1: the tile exists
-    // VSTATS: statistics of this lane's EPC channels over the pixels it stores; shift: the wave's first pixel
-    float sk[EPC], s1[EPC], s2[EPC], cnt = 0.f;
+    WaveStatsLanes<T, CO> vs;                             // VSTATS; shift: the wave's first pixel
+    vs.init();
+    f32x4 acc_s[COF], acc_q[COF];                         // MSTATS (wave_stats_mma)
+    float k_first[COF];                                   // ... shift: the wave's first stored pixel, channel 16 k + r16
 #pragma unroll
-    for (int u = 0; u < EPC; u++) sk[u] = s1[u] = s2[u] = 0.f;
-    // MSTATS: for the 16-channel group k, acc_s = ones^T Y (every row: the column sums of the staged rows Y
-    // [64 pixels][CO]) and acc_q = Y^T Y (its diagonal: the sums of squares), K = pixels.  The operand is the
-    // hardware-transposed read of the staging rows; its K order is the same on both sides of a product.
-    f32x4 acc_s[MSTATS ? COF : 1], acc_q[MSTATS ? COF : 1];
-    float k_first[MSTATS ? COF : 1];                      // shift: the wave's first stored pixel, channel 16 k + r16
-#pragma unroll
-    for (int k = 0; k < (MSTATS ? COF : 1); k++) {
+    for (int k = 0; k < COF; k++) {
         acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         k_first[k] = 0.f;
     }
@@ -242,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
         lds_wait();   // the wave's own rows: no barrier
         asm volatile("" ::: "memory");
         if constexpr (VSTATS) {
-            if (cy == 0) load_vec<T, EPC>(reinterpret_cast<const T*>(stage + lc * (int)sizeof(T)), sk);   // pixel 0 of the row
+            if (cy == 0) load_vec<T, EPC>(reinterpret_cast<const T*>(stage + lc * (int)sizeof(T)), vs.sk);   // pixel 0 of the row
         }
         if (oy < p.Ho) {
             T* orow = out + ((long)(n * p.Ho + oy) * p.Wo) * p.Co;
@@ -253,17 +248,7 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
                 if (ox < p.Wo) {
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + px * SROW + lc * (int)sizeof(T));
                     *reinterpret_cast<uint4*>(orow + (long)ox * p.Co + lc) = v;
-                    if constexpr (VSTATS) {
-                        float f[EPC];
-                        unpack_vec<T, EPC>(v, f);
-#pragma unroll
-                        for (int u = 0; u < EPC; u++) {
-                            const float d = f[u] - sk[u];
-                            s1[u] += d;
-                            s2[u] += d * d;
-                        }
-                        cnt += 1.f;
-                    }
+                    if constexpr (VSTATS) vs.add(v);
                 }
             }
             if constexpr (MSTATS) {
@@ -278,26 +263,7 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
                         *reinterpret_cast<uint4*>(stage + lane * SROW + c) = make_uint4(0u, 0u, 0u, 0u);
                 }
                 asm volatile("" ::: "memory");
-                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                const int q = r16 >> 2, pp = r16 & 3;
-                bf16x8 ones;
-#pragma unroll
-                for (int u = 0; u < 8; u++) ones[u] = (__bf16)1.0f;
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-#pragma unroll
-                    for (int k = 0; k < COF; k++) {
-                        // 16 channels (16 k ..) x 32 pixels (32 h ..): lane (g, q, pp) reads 8 bytes of rows 4 g + q and + 16
-                        const char* a0 = stage + (32 * h + 4 * g + q) * SROW + (2 * k + (pp >> 1)) * 16 + ((pp & 1) << 3);
-                        union {
-                            s16x4 hv[2];
-                            bf16x8 f;
-                        } y;
-                        y.hv[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-                        y.hv[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * SROW));
-                        acc_s[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, y.f, acc_s[k], 0, 0, 0);
-                        acc_q[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y.f, y.f, acc_q[k], 0, 0, 0);
-                    }
+                wave_stats_mma<CO>(stage, SROW, lane, acc_s, acc_q);
                 rows_valid++;
             }
         }
@@ -306,72 +272,14 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     }
     if constexpr (STATS) {
         float* part = reinterpret_cast<float*>(lds);      // [wave][plane k, s1, s2, count][CO]
-        if constexpr (VSTATS) {
-            // lanes of one channel group (lane % LPR) -> the wave's sums
-#pragma unroll
-            for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-                for (int u = 0; u < EPC; u++) {
-                    s1[u] += __shfl_xor(s1[u], off);
-                    s2[u] += __shfl_xor(s2[u], off);
-                }
-                cnt += __shfl_xor(cnt, off);
-            }
-        }
+        if constexpr (VSTATS) vs.reduce();
         lds_barrier();                                    // every wave is done with its staging rows
-        if constexpr (VSTATS) {
-            if (lane < LPR) {
-#pragma unroll
-                for (int u = 0; u < EPC; u++) {
-                    float* e = part + wave * 4 * CO + lc + u;
-                    e[0] = sk[u];
-                    e[CO] = s1[u];
-                    e[2 * CO] = s2[u];
-                    e[3 * CO] = cnt;
-                }
-            }
-        } else {
-            // C/D layout: lane (g, r16), register u = row 4 g + u, column r16.  Column sums: any row; squares:
-            // the diagonal, row = column.  The lanes with g == r16 / 4 hold both for channel 16 k + r16; they
-            // move the plain sums to the shift (this wave's first pixel) so that the rows combine without
-            // cancellation: sum(y - k) = S - n k, sum((y - k)^2) = Q - 2 k S + n k^2.
-            if (g == (r16 >> 2)) {
-                const float nw = (float)(rows_valid * nvalid_px);
-#pragma unroll
-                for (int k = 0; k < COF; k++) {
-                    const float S = acc_s[k][r16 & 3], Q = acc_q[k][r16 & 3], kf = k_first[k];
-                    float* e = part + wave * 4 * CO + k * 16 + r16;
-                    e[0] = kf;
-                    e[CO] = S - nw * kf;
-                    e[2 * CO] = fmaxf(Q - 2.f * kf * S + nw * kf * kf, 0.f);
-                    e[3 * CO] = nw;
-                }
-            }
-        }
+        if constexpr (VSTATS) vs.write_part(part + wave * 4 * CO, lane);
+        else wave_stats_part_mma<CO>(part + wave * 4 * CO, lane, acc_s, acc_q, k_first, (float)(rows_valid * nvalid_px));
         lds_barrier();
-        // waves -> the block's row, moved to wave 0's shift (its first pixel is always inside the image):
-        // sum(x - k0) = s1 + n d, sum((x - k0)^2) = s2 + 2 d s1 + n d^2,  d = k_w - k0
-        if (tid < CO && tid < p.Co) {
-            const float k0 = part[tid];
-            float t1 = 0.f, t2 = 0.f, tc = 0.f;
-#pragma unroll
-            for (int w_ = 0; w_ < 4; w_++) {
-                const float* e = part + w_ * 4 * CO + tid;
-                const float c_ = e[3 * CO];
-                if (c_ > 0.f) {
-                    const float d = e[0] - k0;
-                    t1 += e[CO] + c_ * d;
-                    t2 += e[2 * CO] + 2.f * d * e[CO] + c_ * d * d;
-                    tc += c_;
-                }
-            }
-            const unsigned tile_in_sample = tile - (unsigned)n * tiles_x * tiles_y;
-            float* row = p.tile_stats + (((long)n * p.tile_stats_ts + tile_in_sample) * 4) * p.Co + tid;
-            row[0] = k0;
-            row[p.Co] = t1;
-            row[2 * p.Co] = t2;
-            row[3 * p.Co] = tc;
-        }
+        // wave 0's first pixel (2 ty0, 2 tx0) is always inside the image
+        const unsigned tile_in_sample = tile - (unsigned)n * tiles_x * tiles_y;
+        block_stats_row<CO>(part, tid, p.tile_stats + (((long)n * p.tile_stats_ts + tile_in_sample) * 4) * p.Co, p.Co);
     }
 }
 

@@ -31,6 +31,8 @@ SIGNATURES = {
     'stmi_conv2d_tile_stats_free': (_c_int, [_c_int] * 9),
     'stmi_conv2d_nhwc_fwd_tile_stats': (_c_int, [_vp] * 6 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_rgb_nhwc_fwd': (_c_int, [_vp, _c_float] + [_vp] * 5 + [_c_int] * 7 + [_vp]),
+    'stmi_conv2d_rgb_tile_stats_tiles': (_c_int, [_c_int] * 4),
+    'stmi_conv2d_rgb_nhwc_fwd_tile_stats': (_c_int, [_vp, _c_float] + [_vp] * 4 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_rgb_nhwc_dgrad': (_c_int, [_vp] * 3 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_to3_supported': (_c_int, [_c_int] * 3),
     'stmi_conv2d_to3_nhwc_fwd': (_c_int, [_vp] * 4 + [_c_int] * 6 + [_vp]),

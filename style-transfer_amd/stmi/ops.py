@@ -152,11 +152,18 @@ def conv_tile_stats_tiles(x_shape, kshape, stride, dtype):
 RGB_CONFIGS = ((9, 32), (3, 64), (3, 32))  # (k, co) the 3-channel kernel is built for
 
 
+def conv_rgb_tile_stats_tiles(h, w, co, k):
+    """Statistics rows per sample conv2d_rgb_fwd(tile_stats=...) leaves (0: none for this (k, co))."""
+    return int(_lib.load().stmi_conv2d_rgb_tile_stats_tiles(h, w, co, k))
+
+
 def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=None, relu=False, want_pre=False,
-                   out=None, out_pre=None):
+                   out=None, out_pre=None, tile_stats=None):
     """k x k stride-1 SAME convolution of an fp32 [n,h,w,3] image, computed in `dtype` on
     x * scale - mean[c] (the cast / VGG preprocessing happens while the image is read).
-    w_packed: the [k,k,3,co] weight packed with PACK_FWD_RGB."""
+    w_packed: the [k,k,3,co] weight packed with PACK_FWD_RGB.
+    tile_stats: fp32 [n, conv_rgb_tile_stats_tiles(...), 4, co] that receives the per-tile sums of y for
+    instance_norm_fwd(tile_stats=...); without bias, ReLU and pre-activation copy."""
     n, h, w, c = x_f32.shape
     assert c == 3 and (k, co) in RGB_CONFIGS, (c, k, co)
     _chk(x_f32, 'x_f32', torch.float32)
@@ -170,6 +177,13 @@ def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=Non
         _chk(bias, 'bias', torch.float32, (co,))
     if mean is not None:
         _chk(mean, 'mean', torch.float32, (3,))
+    if tile_stats is not None:
+        assert bias is None and not relu and not want_pre, 'tile statistics: plain convolution only'
+        _chk(tile_stats, 'tile_stats', torch.float32, (n, conv_rgb_tile_stats_tiles(h, w, co, k), 4, co))
+        _conv_call('stmi_conv2d_rgb_nhwc_fwd_tile_stats',
+                   (x_f32.data_ptr(), float(scale), _ptr(mean), w_packed.data_ptr(), y.data_ptr(), tile_stats.data_ptr(),
+                    n, h, w, co, k, _dt(y)), co, n * h * w, 3, k * k, 1)
+        return y
     _conv_call('stmi_conv2d_rgb_nhwc_fwd', (x_f32.data_ptr(), float(scale), _ptr(mean), w_packed.data_ptr(), _ptr(bias),
                                             y.data_ptr(), _ptr(pre), n, h, w, co, k, int(relu), _dt(y)),
                co, n * h * w, 3, k * k, 1)

@@ -134,6 +134,12 @@ class StylizerNet:
                 if 0 < ts <= int(os.environ.get('STMI_TILE_STATS_MAX', '32')) or (
                         ts > 0 and ops.conv_tile_stats_free((batch, h, w, c), b.kshape, s, dtype)):
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
+            # ... the 3-channel first layer, whose statistics pass reads the largest plane of the network
+            # (STMI_TILE_STATS_RGB=0: tuning aid, off)
+            if b.rgb and os.environ.get('STMI_TILE_STATS', '1') == '1' and os.environ.get('STMI_TILE_STATS_RGB', '1') == '1':
+                ts = ops.conv_rgb_tile_stats_tiles(h, w, co, k)
+                if ts > 0:
+                    b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... transposed convolutions: the up-sampling kernel takes the sums from the rows it stores
             # (STMI_TILE_STATS_UP=0: tuning aid, off)
             if kind == 'deconv' and os.environ.get('STMI_TILE_STATS', '1') == '1' and os.environ.get('STMI_TILE_STATS_UP', '1') == '1':
@@ -245,7 +251,7 @@ class StylizerNet:
             if b.kind == 'deconv':
                 ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             elif b.rgb:
-                ops.conv2d_rgb_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out)
+                ops.conv2d_rgb_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out, tile_stats=b.tile_stats)
             elif b.rows == 'in':
                 ops.pixels_to_rows(cur, b.k, -b.pad_left, out=b.rows_buf)
                 ops.conv2d_fwd(b.rows_buf, b.wp_fwd, (b.k, 1, 32, b.co), 1, out=conv_out)

@@ -253,6 +253,41 @@ def test_conv_transpose(cuda, dtype, case):
     assert rel_err(dw, gw_ref) <= TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 16, 64), (1, 13, 45), (3, 40, 33), (1, 3, 2), (1, 300, 130)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_rgb_conv_tile_statistics_feed_instance_norm(cuda, dtype, case):
+    """conv2d_rgb_fwd(tile_stats=) + instance_norm_fwd(tile_stats=) for the stylizer's first layer (9 x 9, 3 -> 32):
+    same output as the plain launch; the sums are those of the STORED tensor, so the statistics equal the separate
+    statistics pass over it and the normalized result meets the oracle.  Ragged 8 x 32 tiles; more rows than
+    the apply blocks fold."""
+    from stmi import ops
+    n, h, w = case
+    k, co = 9, 32
+    x = rnd((n, h, w, 3), 1).abs()
+    wgt = rnd((k, k, 3, co), 2, 0.05)
+    wgt[k // 2, k // 2] += 0.3     # non-zero-mean output
+    scale, shift = rnd((co,), 3) + 1.5, rnd((co,), 4)
+    xd = x.to(cuda, torch.float32)
+    wp = ops.pack_conv_weights(wgt.to(cuda, torch.float32).contiguous(), ops.PACK_FWD_RGB, dtype)
+    ts = ops.conv_rgb_tile_stats_tiles(h, w, co, k)
+    assert ts == -(-h // 8) * -(-w // 32)
+    tiles = torch.full((n, ts, 4, co), float('nan'), dtype=torch.float32, device=cuda)
+    y_conv = ops.conv2d_rgb_fwd(xd, wp, k, co, dtype, tile_stats=tiles)
+    assert torch.equal(y_conv, ops.conv2d_rgb_fwd(xd, wp, k, co, dtype)), 'the statistics must not change the output'
+    assert bool(torch.isfinite(tiles).all())
+    assert tiles[:, :, 3].sum(dim=1).eq(h * w).all(), 'tile pixel counts add up to the plane'
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    y_a, st_a = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU, tile_stats=tiles)
+    y_b, st_b = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU)
+    assert rel_err(st_a[..., 0], st_b[..., 0]) <= 1e-5
+    assert rel_err(st_a[..., 1], st_b[..., 1]) <= 1e-4
+    conv_ref = O.conv2d_same(q(x, dtype), q(wgt, dtype), 1)
+    ref = torch.relu(O.instance_norm(conv_ref, scale.float().double(), shift.float().double()))
+    assert rel_err(y_a, ref) <= TOL[dtype]
+    assert rel_err(y_b, ref) <= TOL[dtype]
+
+
 UP_STAT_CASES = [(2, 6, 5, 128, 64), (1, 7, 40, 64, 32), (3, 9, 70, 128, 64), (1, 1, 1, 64, 32), (1, 135, 130, 64, 32)]
 
 
