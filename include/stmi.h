@@ -99,7 +99,7 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
 int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 /* 1 when the statistics rows of this geometry cost the convolution nothing: planes large enough that ONE sample
  * already runs on the persistent patch kernel, whose loading waves sum the rows while the computing waves store
- * them (no ReLU with them).  Otherwise the rows cost the convolution's epilogue
+ * them (a plain convolution only: no bias, ReLU or second output with them; bf16 layers with 128-channel tiles leave TWO rows per tile, which stmi_conv2d_tile_stats_tiles accounts for).  Otherwise the rows cost the convolution's epilogue
  * about a microsecond per block and pay only while stmi_instance_norm_nhwc_apply_tiles can fold them without
  * a finalize launch (at most 32 per sample).  No counterpart in the reference (a tuning query). */
 int stmi_conv2d_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);

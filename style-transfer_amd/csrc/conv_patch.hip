@@ -423,7 +423,14 @@ __device__ __forceinline__ float lds_read_f32_at(unsigned addr) {
     return v;
 }
 
-template <typename T, int TC, int PW, int NSW, bool STATS>
+//
+// WEPI (bf16, 128-channel tiles, plain convolutions: no bias, mask, addend, ReLU or second output): the MFMA waves
+// finish a tile without the rest of the block.  A wave leaves its 64 pixels x 64 channels as bf16 rows in a staging
+// area of its own (no barrier: nobody else reads them), stores them as 128-byte row pieces, takes the tile
+// statistics from the same rows on the matrix cores (wave_stats_mma; TWO statistics rows per tile, one per pixel
+// half) and starts the next tile.  The DMA waves then have no part in a tile change at all: the four epilogue
+// barriers, the fp32 staging groups and the DMA waves' statistics arithmetic are gone.
+template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false>
 __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;
@@ -569,7 +576,9 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         const int cc = pw * CPW + lane % CPW, rs = lane / CPW;
         const unsigned stage_addr = lds_base + NSW * W_SLOT + 2 * P_BUF;
         auto epilogue_barriers = [&](const TilePos& tp) {
-            if constexpr (!STATS) {
+            if constexpr (WEPI) {
+                // nothing: the MFMA waves finish a tile among themselves
+            } else if constexpr (!STATS) {
 #pragma unroll
                 for (int b = 0; b < EPI_BARRIERS; b++) __builtin_amdgcn_s_barrier();
             } else {
@@ -710,6 +719,11 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         unsigned baddr[TP];
 #pragma unroll
         for (int tp = 0; tp < TP; tp++) baddr[tp] = 0;
+        // WEPI: this wave's staging rows
+        constexpr int SROW = TC * 16 * (int)sizeof(T) + 16;           // bytes of a staged row (this wave's channels)
+        constexpr int S_WAVE = 64 * SROW;
+        char* const stage_w = reinterpret_cast<char*>(stage) + wave * S_WAVE;
+        const unsigned stage_w_addr = lds_base + NSW * W_SLOT + 2 * P_BUF + wave * S_WAVE;
         auto tap_step = [&](int t, unsigned pbuf) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -743,6 +757,83 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
                 static_for<0, 9>([&](auto t_tag) { tap_step(decltype(t_tag)::value, pbuf); });
             }
             mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
+            if constexpr (WEPI) {
+                // this wave's 64 pixels x 16 TC channels -> rows of T of its own; no barrier: nobody else reads them
+#pragma unroll
+                for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+                    for (int tp = 0; tp < TP; tp++) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) v[u] = acc[tc][tp][u] * p.alpha;
+                        store_vec<T, 4>(reinterpret_cast<T*>(stage_w + (tp * 16 + r16) * SROW) + tc * 16 + 4 * g, v);
+                    }
+                lds_wait();
+                asm volatile("" ::: "memory");
+                // out: one eighth of the rows per instruction, pixel 8 j + lane / 8 of the wave's 64, 16 bytes
+                // (8 channels) per lane; all eight reads in flight before the first store.  Everything about the
+                // pixel but lane / 8 is the same for the whole wave: fragment f = wpx TP + j / 2, tile row f / FPR,
+                // first column (f % FPR) 16 + (j & 1) 8.
+                {
+                    const int l3 = lane >> 3;
+                    const int ch = tp0.co0 + wc * (TC * 16) + ((lane & 7) << 3);
+                    u32x4 dv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dv[j] = lds_read16(stage_w_addr + (8 * j + l3) * SROW + ((lane & 7) << 4), 0);
+                    lds_wait();
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        lds_landed(dv[j]);
+                        const int f = wpx * TP + (j >> 1);
+                        const int oy = tp0.ty0 + f / FPR, ox = tp0.tx0 + (f % FPR) * 16 + (j & 1) * 8 + l3;
+                        if (oy < H && ox < W && ch < p.Co)
+                            *reinterpret_cast<u32x4*>((T*)p.out + (((long)tp0.n * H + oy) * W + ox) * p.Co + ch) = dv[j];
+                    }
+                }
+                if constexpr (STATS) {
+                    // The wave's own statistics row (two rows per tile, one per pixel half): sums of the stored
+                    // rows on the matrix cores.  Pixels outside the image were computed but are not part of the
+                    // tensor: their rows become zeros first.
+                    const int rows_in = max(0, min(PH - wpx * (TP / FPR), min(TP / FPR, H - tp0.ty0 - wpx * (TP / FPR))));
+                    const int cols_in = min(PW, W - tp0.tx0);
+                    asm volatile("" ::: "memory");
+                    if (rows_in * cols_in < 64) {
+                        const int fl = lane >> 4;   // fragment of the wave this staged row belongs to
+                        if (fl / FPR >= rows_in || (fl % FPR) * 16 + (lane & 15) >= cols_in) {
+#pragma unroll
+                            for (int cb = 0; cb < TC * 16 * (int)sizeof(T); cb += 16)
+                                *reinterpret_cast<uint4*>(stage_w + lane * SROW + cb) = make_uint4(0u, 0u, 0u, 0u);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    f32x4 acc_s[TC], acc_q[TC];
+#pragma unroll
+                    for (int k = 0; k < TC; k++) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    wave_stats_mma<TC * 16>(stage_w, SROW, lane, acc_s, acc_q);
+                    // C/D layout: the lanes with g == r16 / 4 hold the column sum and the diagonal for channel 16 k + r16
+                    if (g == (r16 >> 2)) {
+                        const float nw = (float)(rows_in * cols_in);
+                        const int tile_in_sample = (tp0.ty0 / PH) * (int)p.pt_div[1] + tp0.tx0 / PW;
+                        float* row = p.tile_stats + (((long)tp0.n * p.tile_stats_ts + tile_in_sample * 2 + wpx) * 4) * p.Co;
+#pragma unroll
+                        for (int k = 0; k < TC; k++) {
+                            const int ch = tp0.co0 + wc * (TC * 16) + k * 16 + r16;
+                            if (ch < p.Co) {
+                                const float S = acc_s[k][r16 & 3], Q = acc_q[k][r16 & 3];
+                                // shift: the wave's first pixel (zero when the whole half is outside the image)
+                                const float kf = to_f32<T>(reinterpret_cast<const T*>(stage_w)[k * 16 + r16]);
+                                row[ch] = kf;
+                                row[p.Co + ch] = S - nw * kf;
+                                row[2 * p.Co + ch] = fmaxf(Q - 2.f * kf * S + nw * kf * kf, 0.f);
+                                row[3 * p.Co + ch] = nw;
+                            }
+                        }
+                    }
+                    lds_wait();
+                    asm volatile("" ::: "memory");
+                }
+                continue;
+            }
             const long img = (long)tp0.n * H;
             conv_epilogue_lds<T, TC, TP, 2, 2, 256, TPG, true>(p, acc, tp0.co0, stage, [&](int pl) -> long {
                 const int f = pl >> 4;
@@ -873,6 +964,13 @@ static bool patch_stats_persistent(const ConvGemmParams& p, int dtype) {
     return patch_persistent_shape(p, dtype, co, patch_tiles(one, co));
 }
 
+// Persistent-statistics geometries whose tiles are 128 channels wide in bf16 run the wave-private epilogue, which
+// leaves TWO statistics rows per tile (one per pixel half).  Geometry only; STMI_PATCH_WEPI=0: off.
+static bool patch_stats_two_rows(const ConvGemmParams& p, int dtype) {
+    return dtype == STMI_BF16 && patch_blk_co(p, dtype) == 128 && p.row_store_ok && patch_stats_persistent(p, dtype) &&
+           STMI_ENV_INT("STMI_PATCH_WEPI", 1) != 0;
+}
+
 static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
     if (p.tile_stats) {
         // forward statistics of a plain convolution only; the decision must not depend on the batch size
@@ -882,16 +980,18 @@ static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
     return patch_persistent_shape(p, dtype, blk_co, patch_tiles(p, blk_co));
 }
 
-template <typename T, int TC, int PW, int NSW, bool STATS>
+template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false>
 static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     constexpr int PH = 128 / PW;
     constexpr size_t kPatch = (size_t)4 * (((PH + 2) * (PW + 2) + 31) / 32) * 8 * 128;
-    constexpr size_t kStage = (size_t)16 * (TC >= 4 ? 2 : 4) * 2 * (32 * TC + 4) * 4;
+    // WEPI: four waves' rows of 16 TC channels of T (+ 16 bytes)
+    constexpr size_t kStage = WEPI ? (size_t)4 * 64 * (16 * TC * sizeof(T) + 16)
+                                    : (size_t)16 * (TC >= 4 ? 2 : 4) * 2 * (32 * TC + 4) * 4;
     constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * kPatch + kStage;
     static_assert(kLds <= 160 * 1024, "operand buffers + staging rows exceed the CU's LDS");
     static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
     if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW, STATS>,
+        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
                            "hipFuncSetAttribute(conv_patch_pers_kernel)");
         if (rc) return rc;
@@ -909,13 +1009,29 @@ static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     q.pt_npers = (unsigned)tiles;
     unsigned grid = (unsigned)(device_cus() / 8 * 8);   // a multiple of the eight XCDs
     if ((long)grid > tiles) grid = (unsigned)((tiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW, STATS>), dim3(grid), dim3(512), kLds, s, q);
+    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>), dim3(grid), dim3(512), kLds, s, q);
     STMI_LAUNCH_CHECK("conv_patch_pers_kernel");
     return STMI_OK;
 }
 
+// The wave-private epilogue (WEPI, see the kernel): plain bf16 convolutions on 128-channel tiles.  STMI_PATCH_WEPI=0: off.
+static bool patch_wepi(const ConvGemmParams& p, int dtype, int blk_co) {
+    if (dtype != STMI_BF16 || blk_co != 128 || !p.row_store_ok) return false;
+    if (p.bias || p.mask || p.addend || p.relu || p.out_pre) return false;
+    if (p.tile_stats && p.tile_stats_mode != 1) return false;
+    if ((long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
+    return STMI_ENV_INT("STMI_PATCH_WEPI", 1) != 0;
+}
+
 template <typename T, int TC>
 static int launch_patch_pers_w(const ConvGemmParams& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && TC == 4) {
+        if (patch_wepi(p, STMI_BF16, 32 * TC)) {
+            if (p.tile_stats)
+                return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, true, true>(p, s) : launch_patch_pers<T, TC, 16, 4, true, true>(p, s);
+            return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, false, true>(p, s) : launch_patch_pers<T, TC, 16, 4, false, true>(p, s);
+        }
+    }
     if (p.tile_stats)
         return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, true>(p, s) : launch_patch_pers<T, TC, 16, 4, true>(p, s);
     return patch_width(p) == 32 ? launch_patch_pers<T, TC, 32, 4, false>(p, s) : launch_patch_pers<T, TC, 16, 4, false>(p, s);
@@ -926,8 +1042,8 @@ static int launch_patch_pers_w(const ConvGemmParams& p, hipStream_t s) {
 int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype, int mode) {
     if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH") || !p.row_store_ok) return 0;
     const int pw = patch_width(p), ph = 128 / pw;
-    (void)mode;
-    return ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw);
+    const int tiles = ceil_div(p.Hi, ph) * ceil_div(p.Wi, pw);
+    return mode == 1 && patch_stats_two_rows(p, dtype) ? 2 * tiles : tiles;
 }
 
 // 1 when the statistics rows of this geometry come at no cost to the launch (the persistent kernel)
@@ -938,10 +1054,17 @@ int conv_patch_stats_free(const ConvGemmParams& p, int dtype) {
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
     const int co = patch_blk_co(p, dtype);
+    if (p.tile_stats && p.tile_stats_mode == 1 && patch_stats_two_rows(p, dtype) && !patch_wepi(p, dtype, co)) {
+        set_error("conv: the tile statistics of this geometry (two rows per tile) come from the plain convolution only: "
+                  "no bias, ReLU, mask, addend or pre-activation copy, fewer than 2^31 output elements");
+        *rc = STMI_ERR_INVALID;
+        return true;
+    }
     if (patch_persistent(p, dtype, co)) {
         if (name)
-            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
-                     dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p), p.tile_stats ? "true" : "false");
+            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<%s, %d, %d, 4, %s, %s>(stmi::ConvGemmParams)",
+                     dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p), p.tile_stats ? "true" : "false",
+                     patch_wepi(p, dtype, co) ? "true" : "false");
         if (dtype == STMI_BF16) *rc = co == 128 ? launch_patch_pers_w<bf16_t, 4>(p, s) : launch_patch_pers_w<bf16_t, 2>(p, s);
         else *rc = launch_patch_pers_w<float, 2>(p, s);
         return true;

@@ -436,6 +436,7 @@ TILE_STAT_CASES = [
     (1, 70, 150, 64, 128),
     (1, 270, 480, 128, 128),    # one sample alone fills three block rounds: the persistent kernel leaves the rows
     (2, 200, 330, 64, 64),      # ... (fp32: two 128-byte chunks, four row slices per tile)
+    (1, 250, 410, 128, 128),    # ... clipped on both borders (bf16: the wave-private epilogue, two rows per tile)
 ]
 
 
@@ -457,20 +458,26 @@ def test_conv_tile_statistics_feed_instance_norm(cuda, dtype, case):
     assert ts > 0, 'this geometry runs on the patch kernel'
     tiles = torch.full((n, ts, 4, co), float('nan'), dtype=torch.float32, device=cuda)
     y_conv = ops.conv2d_fwd(xd, wp, (3, 3, ci, co), 1, tile_stats=tiles)
+    kname = ops.last_conv_kernel()
     assert torch.equal(y_conv, ops.conv2d_fwd(xd, wp, (3, 3, ci, co), 1)), 'the statistics must not change the output'
     assert bool(torch.isfinite(tiles).all())
     assert tiles[:, :, 3].sum(dim=1).eq(h * w).all(), 'tile pixel counts add up to the plane'
     sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
     y_a, st_a = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU, tile_stats=tiles)
     y_b, st_b = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU)
-    # The tile path takes the statistics of the fp32 accumulators, the separate pass those of the stored
-    # (rounded) tensor: the first is held to the oracle tightly, the second as far as bf16 storage allows
-    # (with |mean| >> deviation and few pixels the rounding of the stored values shows in the variance).
+    # The tile path takes the statistics of the fp32 accumulators (one-tile kernel, fp32) or of the stored,
+    # rounded tensor (deferred-store persistent kernel, bf16); the separate pass always those of the stored
+    # tensor.  The first is held to the oracle tightly, the stored kind as far as bf16 storage allows (with
+    # |mean| >> deviation the rounding of the stored values shows in the variance) and to the separate pass.
     conv_ref = O.conv2d_same(q(x, dtype), q(wgt, dtype), 1)
     mean_ref = conv_ref.mean(dim=(1, 2))
     rstd_ref = 1.0 / torch.sqrt(conv_ref.var(dim=(1, 2), unbiased=False) + 1e-3)
-    assert rel_err(st_a[..., 0], mean_ref) <= 1e-4
-    assert rel_err(st_a[..., 1], rstd_ref) <= 1e-3
+    stored = 'pers_kernel' in kname and 'true, true>' in kname
+    if stored:
+        assert rel_err(st_a[..., 0], st_b[..., 0]) <= 1e-5
+        assert rel_err(st_a[..., 1], st_b[..., 1]) <= 1e-4
+    assert rel_err(st_a[..., 0], mean_ref) <= (2e-3 if stored else 1e-4)
+    assert rel_err(st_a[..., 1], rstd_ref) <= (5e-2 if stored else 1e-3)
     assert rel_err(st_b[..., 0], mean_ref) <= (1e-4 if dtype == torch.float32 else 2e-3)
     assert rel_err(st_b[..., 1], rstd_ref) <= (1e-3 if dtype == torch.float32 else 5e-2)
     ref = torch.relu(O.instance_norm(conv_ref, scale.float().double(), shift.float().double()))
