@@ -303,11 +303,13 @@ PackGeom pack_geom(int kh, int kw, int ci, int co, int mode) {
 template <typename T>
 __device__ __forceinline__ void pack_range(const float* __restrict__ w, T* __restrict__ out, int kh, int kw, int ci,
                                            int co, int mode, const PackGeom& g, long first, long stride) {
-    const long total = (long)g.ntaps * g.rows_pad * g.kpad;
-    for (long idx = first; idx < total; idx += stride) {
-        const int e = (int)(idx % g.kpad);
-        const int row = (int)((idx / g.kpad) % g.rows_pad);
-        const int t = (int)(idx / ((long)g.kpad * g.rows_pad));
+    // 32-bit indices (the launchers check the packed size): three 64-bit divisions per element were most of the kernel
+    const unsigned total = (unsigned)g.ntaps * g.rows_pad * g.kpad, kpad = g.kpad, per_tap = kpad * g.rows_pad;
+    for (unsigned idx = (unsigned)first; idx < total; idx += (unsigned)stride) {
+        const int t = (int)(idx / per_tap);
+        const unsigned in_tap = idx - t * per_tap;
+        const int row = (int)(in_tap / kpad);
+        const int e = (int)(in_tap - row * kpad);
         float v = 0.f;
         if (mode == STMI_PACK_FWD_ROWOUT) {
             if (row < g.rows && e < g.klen) v = w[(((long)t * kw + row / co) * ci + e) * co + row % co];
@@ -378,6 +380,7 @@ int pack_weights_multi_impl(const float* src, void* dst, const stmi_pack_desc* d
             b.e[i].src_off = d.src_off; b.e[i].dst_off = d.dst_off;
             b.e[i].kh = d.kh; b.e[i].kw = d.kw; b.e[i].ci = d.ci; b.e[i].co = d.co; b.e[i].mode = d.mode;
             b.e[i].g = pack_geom(d.kh, d.kw, d.ci, d.co, d.mode);
+            STMI_REQUIRE((long)b.e[i].g.ntaps * b.e[i].g.rows_pad * b.e[i].g.kpad < (1L << 31), "pack_conv_weights: packed tensor too large");
         }
         if (dtype == STMI_BF16)
             hipLaunchKernelGGL(pack_weights_multi_kernel<bf16_t>, dim3(48, cnt), dim3(256), 0, s, src, (bf16_t*)dst, b);
@@ -630,6 +633,7 @@ int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n
 int pack_weights_impl(const float* w, void* out, int kh, int kw, int ci, int co, int mode, int dtype, hipStream_t s) {
     const PackGeom g = pack_geom(kh, kw, ci, co, mode);
     const long total = (long)g.ntaps * g.rows_pad * g.kpad;
+    STMI_REQUIRE(total < (1L << 31), "pack_conv_weights: packed tensor too large");
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     if (dtype == STMI_BF16)
         hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)out, kh, kw, ci, co, mode, g);

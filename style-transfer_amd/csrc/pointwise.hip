@@ -371,18 +371,24 @@ __global__ void bump_step_kernel(int* step);
 // captured graph replays it without a device-side table.
 struct ZeroBatch {
     float* p[STMI_ZERO_MULTI_MAX];
-    long end[STMI_ZERO_MULTI_MAX];   // running ends of the concatenated ranges, in floats
+    long len[STMI_ZERO_MULTI_MAX];   // floats of the range
     int n;
     int* step;
 };
 
+// grid (blocks, ranges): a block clears a part of ONE range (no search per element), 16 bytes per thread and
+// store where the buffer is 16-byte aligned
 __global__ __launch_bounds__(256) void zero_multi_kernel(const ZeroBatch b) {
-    if (b.step && blockIdx.x == 0 && threadIdx.x == 0) b.step[0] += 1;
-    const long total = b.end[b.n - 1];
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int k = 0;
-        while (i >= b.end[k]) k++;
-        b.p[k][i - (k ? b.end[k - 1] : 0)] = 0.f;
+    if (b.step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) b.step[0] += 1;
+    float* base = b.p[blockIdx.y];
+    const long len = b.len[blockIdx.y];
+    const long first = blockIdx.x * (long)blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if ((((uintptr_t)base) & 15) == 0) {
+        const long quads = len >> 2;
+        for (long q = first; q < quads; q += stride) reinterpret_cast<f32x4*>(base)[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (blockIdx.x == 0 && threadIdx.x < (len & 3)) base[(quads << 2) + threadIdx.x] = 0.f;
+    } else {
+        for (long i = first; i < len; i += stride) base[i] = 0.f;
     }
 }
 
@@ -393,9 +399,9 @@ int zero_multi_impl(float* const* ptrs, const long* counts, int n, int* step, hi
     int m = 0;
     for (int i = 0; i < n; i++) {
         if (counts[i] <= 0) continue;
-        run += counts[i];
+        run = counts[i] > run ? counts[i] : run;   // the longest range sizes the grid
         b.p[m] = ptrs[i];
-        b.end[m] = run;
+        b.len[m] = counts[i];
         m++;
     }
     b.n = m;
@@ -405,7 +411,7 @@ int zero_multi_impl(float* const* ptrs, const long* counts, int n, int* step, hi
         STMI_LAUNCH_CHECK("bump_step_kernel");
         return STMI_OK;
     }
-    hipLaunchKernelGGL(zero_multi_kernel, dim3(flat_blocks(run)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(flat_blocks((run + 3) / 4), m), dim3(256), 0, s, b);
     STMI_LAUNCH_CHECK("zero_multi_kernel");
     return STMI_OK;
 }
@@ -415,12 +421,22 @@ __global__ void bump_step_kernel(int* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long count, float lr, float b1, float b2, float eps,
-                            float grad_scale, const int* step_dev, int t_host) {
-    const int t = step_dev ? step_dev[0] : t_host;
-    // double keeps 1-b2^t exact enough for small t (b2 = .999)
-    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+// lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), in double (1 - b2^t must stay exact for small t, b2 = .999); one thread
+// of the block works it out (two double pow are hundreds of instructions: not something for every thread).
+__device__ __forceinline__ float adam_lr_t(float lr, float b1, float b2, const int* step_dev, int t_host, float* sh) {
+    if (threadIdx.x == 0) {
+        const int t = step_dev ? step_dev[0] : t_host;
+        *sh = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    }
+    __syncthreads();
+    return *sh;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long count, float lr, float b1, float b2, float eps,
+                                                   float grad_scale, const int* step_dev, int t_host) {
+    __shared__ float sh;
+    const float lr_t = adam_lr_t(lr, b1, b2, step_dev, t_host, &sh);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -431,13 +447,46 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// the same on 16-byte aligned buffers: four parameters per thread and access; the tail (count % 4) is the last block's
+__global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long count, float lr, float b1, float b2,
+                                                       float eps, float grad_scale, const int* step_dev, int t_host) {
+    __shared__ float sh;
+    const float lr_t = adam_lr_t(lr, b1, b2, step_dev, t_host, &sh);
+    const long quads = count >> 2;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
+        const f32x4 gi = reinterpret_cast<const f32x4*>(g)[q] * grad_scale;
+        const f32x4 mi = b1 * reinterpret_cast<const f32x4*>(m)[q] + (1.f - b1) * gi;
+        const f32x4 vi = b2 * reinterpret_cast<const f32x4*>(v)[q] + (1.f - b2) * gi * gi;
+        f32x4 pi = reinterpret_cast<const f32x4*>(p)[q];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pi[u] -= lr_t * mi[u] / (sqrtf(vi[u]) + eps);
+        reinterpret_cast<f32x4*>(m)[q] = mi;
+        reinterpret_cast<f32x4*>(v)[q] = vi;
+        reinterpret_cast<f32x4*>(p)[q] = pi;
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        for (long i = (quads << 2) + threadIdx.x; i < count; i += blockDim.x) {
+            const float gi = g[i] * grad_scale;
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
 int adam_impl(float* p, const float* g, float* m, float* v, long count, float lr, float b1, float b2, float eps,
               float grad_scale, int* step_dev, int t, hipStream_t s) {
     if (step_dev && t >= 0) {
         hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, s, step_dev);
         STMI_LAUNCH_CHECK("bump_step_kernel");
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(count)), dim3(256), 0, s, p, g, m, v, count, lr, b1, b2, eps, grad_scale, (const int*)step_dev, t);
+    if (((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && count >= 4)
+        hipLaunchKernelGGL(adam_vec_kernel, dim3(flat_blocks(count >> 2)), dim3(256), 0, s, p, g, m, v, count, lr, b1, b2, eps, grad_scale, (const int*)step_dev, t);
+    else
+        hipLaunchKernelGGL(adam_kernel, dim3(flat_blocks(count)), dim3(256), 0, s, p, g, m, v, count, lr, b1, b2, eps, grad_scale, (const int*)step_dev, t);
     STMI_LAUNCH_CHECK("adam_kernel");
     return STMI_OK;
 }

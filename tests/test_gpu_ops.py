@@ -650,6 +650,36 @@ def test_adam_tf1_and_small_ops(cuda):
     assert ops.clip_(z, 0.0, 1.0).cpu().tolist() == [0.0, 0.5, 1.0]
 
 
+def test_adam_and_step_begin_on_odd_and_unaligned_buffers(cuda):
+    """The 16-byte forms of Adam and of the one-launch clear: lengths that are not multiples of four, views that
+    start off a 16-byte boundary, buffers of very different sizes, the step counter."""
+    from stmi import ops
+    from oracle import loops as L
+    rng = np.random.default_rng(1)
+    for n, off in ((1003, 0), (1003, 1), (5, 0), (3, 2), (70001, 0)):
+        p, g = rng.standard_normal(n), rng.standard_normal(n)
+        hold = [torch.zeros(n + 4, device=cuda) for _ in range(4)]
+        pd, gd, md, vd = (h[off:off + n] for h in hold)
+        pd.copy_(torch.tensor(p, dtype=torch.float32))
+        gd.copy_(torch.tensor(g, dtype=torch.float32))
+        step = torch.zeros(1, dtype=torch.int32, device=cuda)
+        ops.adam_tf1(pd, gd, md, vd, 0.02, 0.9, 0.999, 1e-8, step_dev=step)
+        want, _, _ = L.adam_tf1(p, g, np.zeros(n), np.zeros(n), 1, 0.02, 0.9, 0.999, 1e-8)
+        assert step.item() == 1
+        assert rel_err(pd, torch.tensor(want)) <= 1e-5, (n, off)
+        for h, view in zip(hold, (pd, gd, md, vd)):      # nothing outside the view was touched
+            assert h[:off].abs().sum().item() == 0 and h[off + n:].abs().sum().item() == 0
+    big = torch.ones(100003, device=cuda)
+    bufs = [big[1:], torch.ones(7, device=cuda), torch.ones(4096, device=cuda)[3:4001], torch.ones(1, device=cuda),
+            torch.ones(262144, device=cuda)]
+    step = torch.full((1,), 41, dtype=torch.int32, device=cuda)
+    ops.ZeroList(bufs, step_dev=step).run()
+    assert step.item() == 42
+    for b in bufs:
+        assert b.abs().sum().item() == 0
+    assert big[0].item() == 1.0
+
+
 def test_error_reporting(cuda):
     from stmi import lib, ops
     x = torch.zeros((1, 4, 4, 3), device=cuda)
