@@ -23,6 +23,7 @@ struct ConvGemmParams {
     int row_store_ok;  // Co and the tensors' alignment allow whole-row 16-byte stores (set by the launcher)
     unsigned pt_div[3], pt_magic[3];  // patch kernel: channel tiles, tiles per row, tile rows per image (+ reciprocals)
     unsigned pt_npers;                // persistent patch kernel: tiles of the launch
+    int pt_wepi;                      // one-tile patch kernel: the MFMA waves finish the tile among themselves
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the

@@ -101,6 +101,124 @@ constexpr int in_flight_ok(int nsw, int ni_w, bool last, int t) {
 
 }  // namespace
 
+// One float from LDS at a byte address plus an immediate offset (no address arithmetic per row); asm so that
+// the read is not merged or moved over the barriers around it.  The caller waits (lds_wait) before use.
+template <int OFF>
+__device__ __forceinline__ float lds_read_f32_at(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+// Epilogue of the one-tile kernel among the four MFMA waves alone, for plain bf16 convolutions that leave tile
+// statistics (ConvGemmParams::pt_wepi).  A wave stages its 64 pixels x 16 TC channels as rows of T in a free patch
+// buffer (no barrier: nobody else reads them; bias and alpha go in before) and stores them as whole row pieces.
+// The statistics (mode 1) are sums of the stored rows on the matrix cores (wave_stats_mma); the two pixel halves
+// of a channel half meet in `spart` behind ONE barrier of the four waves (the DMA waves have left the kernel),
+// one row per tile.  The generic epilogue needs two to four barriers of all eight waves, fp32 staging and a column pass.
+// LDS reads behind the global stores are inline asm: a compiler-visible one would be preceded by vmcnt(0), i.e.
+// by the stores' round trip to memory.
+template <typename T, int TC, int PW>
+__device__ __forceinline__ void patch_wave_epilogue(const ConvGemmParams& p, const f32x4 (&acc)[TC][4], char* stage_w,
+                                                    unsigned stage_w_addr, unsigned spart_addr, int wave, int lane, int n,
+                                                    int ty0, int tx0, int co0) {
+    static_assert(sizeof(T) == 2 && (TC == 2 || TC == 4), "bf16 tiles of 64 or 128 channels");
+    constexpr int TP = 4, PH = 128 / PW, FPR = PW / 16;
+    constexpr int WCH = TC * 16;                          // channels of a wave
+    constexpr int SROW = WCH * (int)sizeof(T) + 16;       // bytes of a staged row
+    constexpr int LPR = WCH / 8;                          // lanes per staged row (16 bytes each)
+    constexpr int PXP = 64 / LPR, NPASS = LPR;            // pixels per pass, passes
+    const int H = p.Hi, W = p.Wi;
+    const int wc = wave >> 1, wpx = wave & 1, g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int tc = 0; tc < TC; tc++) {
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        const int ch = co0 + wc * WCH + tc * 16 + 4 * g;
+        if (p.bias) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ch + u < p.Co) bias[u] = p.bias[ch + u];
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (acc[tc][tp][u] + bias[u]) * p.alpha;
+            store_vec<T, 4>(reinterpret_cast<T*>(stage_w + (tp * 16 + r16) * SROW) + tc * 16 + 4 * g, v);
+        }
+    }
+    lds_wait();
+    asm volatile("" ::: "memory");
+    if (p.tile_stats) {
+        // this wave's half of the tile's pixels; rows of pixels outside the image become zeros first
+        const int rows_in = max(0, min(TP / FPR, H - ty0 - wpx * (TP / FPR))), cols_in = min(PW, W - tx0);
+        if (rows_in * cols_in < 64) {
+            const int fl = lane >> 4;
+            if (fl / FPR >= rows_in || (fl % FPR) * 16 + (lane & 15) >= cols_in) {
+#pragma unroll
+                for (int cb = 0; cb < WCH * (int)sizeof(T); cb += 16)
+                    *reinterpret_cast<uint4*>(stage_w + lane * SROW + cb) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        asm volatile("" ::: "memory");
+        f32x4 acc_s[TC], acc_q[TC];
+#pragma unroll
+        for (int k = 0; k < TC; k++) acc_s[k] = acc_q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_stats_mma<WCH>(stage_w, SROW, lane, acc_s, acc_q);
+        // C/D layout: the lanes with g == r16 / 4 hold the column sum and the diagonal for channel 16 k + r16
+        if (g == (r16 >> 2)) {
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const unsigned a = spart_addr + ((wave * 2 * WCH) + k * 16 + r16) * 4;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(acc_s[k][r16 & 3]) : "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(acc_q[k][r16 & 3]), "n"(WCH * 4) : "memory");
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();                      // the four MFMA waves: both halves' sums are in LDS
+        asm volatile("" ::: "memory");
+        if (wpx == 0 && lane < WCH) {
+            const unsigned a0 = spart_addr + (wave * 2 * WCH + lane) * 4, a1 = a0 + 2 * WCH * 4;   // this wave, wave + 1
+            const float s0 = lds_read_f32_at<0>(a0), q0 = lds_read_f32_at<WCH * 4>(a0);
+            const float s1 = lds_read_f32_at<0>(a1), q1 = lds_read_f32_at<WCH * 4>(a1);
+            unsigned kraw;
+            asm volatile("ds_read_u16 %0, %1" : "=v"(kraw) : "v"(stage_w_addr + lane * 2) : "memory");
+            lds_wait();
+            asm volatile("" : "+v"(kraw));
+            const float S = s0 + s1, Q = q0 + q1;
+            const float kf = __uint_as_float(kraw << 16);   // the tile's first pixel
+            const float nt = (float)(min(PH, H - ty0) * min(PW, W - tx0));
+            const int ch = co0 + wc * WCH + lane;
+            if (ch < p.Co) {
+                const int tile_in_sample = (ty0 / PH) * (int)p.pt_div[1] + tx0 / PW;
+                float* row = p.tile_stats + (((long)n * p.tile_stats_ts + tile_in_sample) * 4) * p.Co + ch;
+                row[0] = kf;
+                row[p.Co] = S - nt * kf;
+                row[2 * p.Co] = fmaxf(Q - 2.f * kf * S + nt * kf * kf, 0.f);
+                row[3 * p.Co] = nt;
+            }
+        }
+    }
+    // out: pixel PXP j + lane / LPR of the wave's 64, 16 bytes (8 channels) per lane, all reads in flight first
+    const int lr = lane / LPR, lchunk = lane % LPR;
+    const int ch = co0 + wc * WCH + lchunk * 8;
+    u32x4 dv[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) dv[j] = lds_read16(stage_w_addr + (PXP * j + lr) * SROW + (lchunk << 4), 0);
+    lds_wait();
+    T* out = (T*)p.out;
+#pragma unroll
+    for (int j = 0; j < NPASS; j++) {
+        lds_landed(dv[j]);
+        const int px = PXP * j + lr;
+        const int f = wpx * TP + (px >> 4);
+        const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (px & 15);
+        if (oy < H && ox < W && ch < p.Co)
+            *reinterpret_cast<u32x4*>(out + (((long)n * H + oy) * W + ox) * p.Co + ch) = dv[j];
+    }
+}
+
 // ONE: the layer has a single channel chunk (Cin * sizeof(T) == 128): every instruction runs once,
 // i.e. misses the instruction cache once, so that instantiation keeps its code small (rolled tap
 // loop in the MFMA waves, no next-patch logic in the DMA waves).
@@ -239,6 +357,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         }
         chunk_body(std::true_type{}, nchunks - 1);
         STMI_STAMP(2);
+        if constexpr (sizeof(T) == 2 && (TC == 2 || TC == 4)) {
+            if (p.pt_wepi) return;   // the MFMA waves finish the tile among themselves (patch_wave_epilogue)
+        }
     } else {
         // ------------------------------------------------------------------ consumer waves
         const int wc = wave >> 1, wpx = wave & 1;
@@ -342,6 +463,17 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         }
         mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
         STMI_STAMP(2);
+        if constexpr (sizeof(T) == 2 && (TC == 2 || TC == 4)) {
+            if (p.pt_wepi) {
+                // free LDS: the patch buffer the last chunk did not use (read last before that chunk's first
+                // barrier), and the ring slot after the last step's (consumed before the last step's barrier)
+                const unsigned stage_off = NSW * W_SLOT + (nchunks & 1) * P_BUF + wave * (64 * (TC * 32 + 16));
+                patch_wave_epilogue<T, TC, PW>(p, acc, reinterpret_cast<char*>(lds) + stage_off, lds_base + stage_off,
+                                               lds_base + slot * W_SLOT, wave, lane, n, ty0, tx0, co0);
+                STMI_STAMP(3);
+                return;
+            }
+        }
     }
 
     // epilogue
@@ -413,15 +545,6 @@ constexpr int in_flight_ok_pp(int nsw, int ni_w, int pp, bool last, int t) {
 // waves -- idle there, their next loads already issued -- add up the same rows by column (lane = channel x
 // one of 256 / BLK_CO row slices, the slices then added across lanes): one statistics row per tile, as the
 // plain kernel leaves, at 2 % of the launch (1080p residual layers, measured).
-// One float from LDS at a byte address plus an immediate offset (no address arithmetic per row); asm so that
-// the read is not merged or moved over the barriers around it.  The caller waits (lds_wait) before use.
-template <int OFF>
-__device__ __forceinline__ float lds_read_f32_at(unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
 
 //
 // WEPI (bf16, 128-channel tiles, plain convolutions: no bias, mask, addend, ReLU or second output): the MFMA waves
@@ -912,6 +1035,15 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
         }
     }
     STMI_REQUIRE(tiles < (1L << 31), "conv: too many tiles for one launch");
+    // The MFMA waves' own epilogue (patch_wave_epilogue): plain bf16 convolutions on tiles of 64 / 128 channels that
+    // leave tile statistics (10.2 -> 9.7 us on a residual layer of a training batch).  Launches without statistics
+    // gain nothing from it (+-0.5 us, measured on every VGG layer: their tail is the stores' drain, not the
+    // barriers), and single-chunk layers lose their second resident block to its staging rows.
+    // STMI_PATCH_WEPI1=0: off (tuning aid).
+    if constexpr (sizeof(T) == 2 && (TC == 2 || TC == 4)) {
+        q.pt_wepi = !ONE && p.row_store_ok && !p.mask && !p.addend && !p.relu && !p.out_pre && p.tile_stats &&
+                    p.tile_stats_mode == 1 && STMI_ENV_INT("STMI_PATCH_WEPI1", 1) != 0;
+    }
     // a layer with a single channel chunk never touches the second patch buffer
     const size_t lds_bytes = ONE ? kLds - 4 * kPatchPieces * 8 * 128 : kLds;
     hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW, ONE>), dim3((unsigned)tiles), dim3(512), lds_bytes, s, q);

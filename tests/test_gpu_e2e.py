@@ -279,7 +279,9 @@ def test_gatys_steps_bf16(cuda):
     # graph replay against eager launches: the same kernels in the same order; the Gram matrices are summed
     # by float atomics whose order is free, so the pictures agree closely, not bit for bit
     assert psnr(final[(torch.bfloat16, False)][1], final[(torch.bfloat16, True)][1]) >= 45.0
-    assert abs(final[(torch.bfloat16, False)][0] - final[(torch.bfloat16, True)][0]) <= 1e-3 * f32[0]
+    # (measured over repeated runs: the 30-step bf16 loss ends at one of two values 1.1e-3 apart, in either mode,
+    # and the fp32 one moves by 2 % from run to run: one flipped bf16 rounding early on is amplified by Adam)
+    assert abs(final[(torch.bfloat16, False)][0] - final[(torch.bfloat16, True)][0]) <= 5e-3 * f32[0]
 
 
 def test_style_swap_after_graph_capture(cuda):

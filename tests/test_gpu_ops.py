@@ -465,14 +465,23 @@ def test_conv_tile_statistics_feed_instance_norm(cuda, dtype, case):
     sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
     y_a, st_a = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU, tile_stats=tiles)
     y_b, st_b = ops.instance_norm_fwd(y_conv, sd, hd, ops.ACT_RELU)
-    # The tile path takes the statistics of the fp32 accumulators (one-tile kernel, fp32) or of the stored,
-    # rounded tensor (deferred-store persistent kernel, bf16); the separate pass always those of the stored
-    # tensor.  The first is held to the oracle tightly, the stored kind as far as bf16 storage allows (with
-    # |mean| >> deviation the rounding of the stored values shows in the variance) and to the separate pass.
+    # The tile path takes the statistics of the fp32 accumulators (fp32, and bf16 tiles narrower than 64
+    # channels) or of the stored, rounded tensor (bf16: the MFMA waves' own epilogue sums the rows it
+    # stores); the separate pass always those of the stored tensor.  The first is held to the oracle
+    # tightly, the stored kind as far as bf16 storage allows (with |mean| >> deviation the rounding of the
+    # stored values shows in the variance) and to the separate pass.
     conv_ref = O.conv2d_same(q(x, dtype), q(wgt, dtype), 1)
     mean_ref = conv_ref.mean(dim=(1, 2))
     rstd_ref = 1.0 / torch.sqrt(conv_ref.var(dim=(1, 2), unbiased=False) + 1e-3)
-    stored = 'pers_kernel' in kname and 'true, true>' in kname
+    import re
+    mt = re.search(r'(conv_patch\w*)<__bf16, ([^>]*)>', kname)
+    stored = False
+    if mt is not None:
+        args = [a.strip() for a in mt.group(2).split(',')]
+        if mt.group(1) == 'conv_patch_kernel':      # T, TC, PW, NSW, ONE: 64- / 128-channel tiles of several chunks
+            stored = args[0] in ('2', '4') and args[3] == 'false'
+        else:                                       # persistent: T, TC, PW, NSW, STATS, WEPI
+            stored = args[4] == 'true'
     if stored:
         assert rel_err(st_a[..., 0], st_b[..., 0]) <= 1e-5
         assert rel_err(st_a[..., 1], st_b[..., 1]) <= 1e-4
