@@ -37,13 +37,13 @@ def demangled(name):
         a = t(m.group(1))
         return ('void stmi::conv_to3_kernel<%s, %s, %s, %s>(%s const*, %s const*, %s const*, %s*, int, int, int)'
                 % (a, m.group(2), m.group(3), m.group(4), a, a, a, a))
-    m = re.match(r'_ZN4stmi\d+(\w+?)I(DF16b|f)((?:Li\d+E)+)(Lb[01]E)?EEvNS_\d+\w+E', name)
+    m = re.match(r'_ZN4stmi\d+(\w+?)I(DF16b|f)((?:Li\d+E)+)((?:Lb[01]E)*)EEvNS_\d+\w+E', name)
     if not m:
         # the profiler's own demangler renders "__bf16, 1" (DF16bLi1E) as "bool _Accum, int, E"
         return name.replace('<bool _Accum, int, E', '<__bf16, 1')
     args = ', '.join(re.findall(r'Li(\d+)E', m.group(3)))
-    if m.group(4):
-        args += ', true' if m.group(4) == 'Lb1E' else ', false'
+    for b in re.findall(r'Lb([01])E', m.group(4)):
+        args += ', true' if b == '1' else ', false'
     return 'void stmi::%s<%s, %s>(stmi::%s)' % (m.group(1), '__bf16' if m.group(2) == 'DF16b' else 'float', args,
                                                  'WgradParams' if 'wgrad' in m.group(1) else 'ConvGemmParams')
 

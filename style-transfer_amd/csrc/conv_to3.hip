@@ -48,7 +48,15 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W + PW - 1) / PW, tiles_y = (H + PH - 1) / PH;
-    int t = blockIdx.x;
+    // Blocks b and b + 8 run on the same XCD: every XCD gets one contiguous run of tiles (row-major), so that the
+    // halo a tile shares with its neighbours is fetched through ONE 4 MiB L2 (in plain block order the eight L2s
+    // each fetched it: 2.5x the input from memory, by the counters).
+    int t;
+    {
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        const unsigned per = G >> 3, rem = G & 7, xcd = b & 7, slot = b >> 3;
+        t = (int)((xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot);
+    }
     const int n = t / (tiles_x * tiles_y);
     t -= n * tiles_x * tiles_y;
     const int ty0 = (t / tiles_x) * PH, tx0 = (t % tiles_x) * PW;
