@@ -305,6 +305,11 @@ static int launch_pc_typed(const ConvGemmParams& p, int rb, hipStream_t s, char*
         return shallow ? launch_pc<T, 1, 8, 128, 2>(p, s, name, name_len, tname) : launch_pc<T, 1, 4, 128>(p, s, name, name_len, tname);
     if (shallow && p.co_pad % 128 != 0) return launch_pc<T, 2, 4, 128, 2>(p, s, name, name_len, tname);
     int cfg = STMI_ENV_INT("STMI_PC_CFG", 0);
+    // Launches of many block rounds and few K steps (the 64 -> 128 stride-2 layer of a 1080p batch: 126 rounds of
+    // nine steps) take the 2-slot ring as well: 48 KB of LDS lets two blocks share a CU, so one block's start and
+    // epilogue run under the other's steps (885 -> about 750 us per launch; a training batch, one round, is unmoved).
+    if (cfg == 3 || (cfg == 0 && wide && p.ntaps * (p.klen / (128 / (int)sizeof(T))) <= 9 && pc_tiles(p, 64, 128) >= 4 * 256))
+        return launch_pc<T, 2, 4, 128, 2>(p, s, name, name_len, tname);
     if (cfg != 1 && cfg != 2) cfg = p.co_pad % 128 == 0 && pc_tiles(p, 128, 64) >= 192 ? 1 : 2;
     if (cfg == 1 && (p.co_pad % 128 != 0 || sizeof(T) == 4)) cfg = 2;  // the fp32 128 x 64 tile spills registers
     if (cfg == 1) return launch_pc<T, 4, 2, 128>(p, s, name, name_len, tname);
