@@ -437,6 +437,8 @@ TILE_STAT_CASES = [
     (1, 270, 480, 128, 128),    # one sample alone fills three block rounds: the persistent kernel leaves the rows
     (2, 200, 330, 64, 64),      # ... (fp32: two 128-byte chunks, four row slices per tile)
     (1, 250, 410, 128, 128),    # ... clipped on both borders (bf16: the wave-private epilogue, two rows per tile)
+    (1, 250, 410, 128, 96),     # ... and a channel count that does not fill the last 128-channel tile
+    (2, 30, 40, 128, 96),
 ]
 
 
