@@ -97,11 +97,13 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
  * [sample][tile][plane][channel], planes = shift k, sum(y - k), sum((y - k)^2), pixel count.  Consumed by
  * stmi_instance_norm_nhwc_apply_tiles.  y and y_pre must be 16-byte aligned. */
 int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
-/* 1 when the statistics rows of this geometry cost the convolution nothing: planes large enough that ONE sample
- * already runs on the persistent patch kernel, whose loading waves sum the rows while the computing waves store
- * them (a plain convolution only: no bias, ReLU or second output with them; bf16 layers with 128-channel tiles leave TWO rows per tile, which stmi_conv2d_tile_stats_tiles accounts for).  Otherwise the rows cost the convolution's epilogue
- * about a microsecond per block and pay only while stmi_instance_norm_nhwc_apply_tiles can fold them without
- * a finalize launch (at most 32 per sample).  No counterpart in the reference (a tuning query). */
+/* 1 when the statistics rows of this geometry cost the convolution next to nothing: planes large enough that ONE
+ * sample already runs on the persistent patch kernel, which sums the rows it stores (on the matrix cores, or in
+ * its loading waves while the computing waves store).  With them the convolution must be plain: no bias, ReLU
+ * or second output; bf16 layers with 128-channel tiles leave TWO rows per tile, which
+ * stmi_conv2d_tile_stats_tiles accounts for.  Otherwise the rows cost the convolution's epilogue up to a
+ * microsecond per block and pay only while stmi_instance_norm_nhwc_apply_tiles can fold them without a
+ * finalize launch (at most 32 per sample).  No counterpart in the reference (a tuning query). */
 int stmi_conv2d_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int stmi_conv2d_nhwc_fwd_tile_stats(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
                                     float* tile_stats,
