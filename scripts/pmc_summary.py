@@ -2,7 +2,7 @@
 
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide (16 B per lane) reads at half
 their size, so it is doubled (the kernels here read 16 B per lane throughout)."""
-import csv, glob, json, sys, collections, re
+import csv, glob, json, os, sys, collections, re
 
 def step_rows(path):
     """Rows of the last two training steps only (a step ends with the multi-tensor weight repack): the run
@@ -16,7 +16,7 @@ def step_rows(path):
 
 
 def load(d):
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    f = max(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime)   # the newest pass (merged copies keep old ones)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in step_rows(f):
         agg[r['Kernel_Name']][0] += 1
@@ -54,7 +54,7 @@ def load_mfma(d):
     if not files:
         return agg
     seen = set()
-    for r in step_rows(files[0]):
+    for r in step_rows(max(files, key=os.path.getmtime)):
         k = r['Kernel_Name']
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
@@ -77,6 +77,22 @@ for k, (n, v) in fe.items():
         out[demangled(k)].update({
             'mfma_flop_per_launch': round(m['SQ_INSTS_VALU_MFMA_MOPS_BF16'] * 512 / m['launches']),
             'mfma_busy_frac': round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024), 4)})
+# Groups as bench.py's roofline names its bandwidth-bound calls: one instance-norm forward = its statistics, finalize
+# and apply launches; bytes per call = the traffic of all of them / the number of apply launches.
+def group(pattern, calls_of):
+    ks = [k for k in out if re.search(pattern, k)]
+    calls = sum(out[k]['launches'] for k in ks if re.search(calls_of, k))
+    if not ks or not calls:
+        return None
+    tot = lambda f: sum(out[k][f] * out[k]['launches'] for k in ks)
+    return {'launches': calls, 'fetch_bytes_per_launch': round(tot('fetch_bytes_per_launch') / calls),
+            'write_bytes_per_launch': round(tot('write_bytes_per_launch') / calls),
+            'bytes_per_launch': round(tot('bytes_per_launch') / calls), 'kernels': sorted(ks)}
+for gname, pat, calls_of in (('instance_norm_fwd', r'in_stats|in_apply', r'in_apply'),
+                             ('instance_norm_bwd', r'in_bwd_reduce|in_bwd_apply', r'in_bwd_apply')):
+    g_ = group(pat, calls_of)
+    if g_:
+        out[gname] = g_
 json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 '
                      'GRBM_GUI_ACTIVE), separate passes, bench.py --steps 3 --warmup 1 with STMI_SERIAL=gwc, launches of the last two steps only (no concurrent '
                      'kernels: the counters are chip-wide); FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64); '
