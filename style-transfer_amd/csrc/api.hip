@@ -186,6 +186,7 @@ int stmi_conv2d_nhwc_fwd_tile_stats(const void* x, const void* w_packed_fwd, con
                                     float* tile_stats, int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                     int relu, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_fwd_tile_stats", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x && w_packed_fwd && y && tile_stats, "conv2d_nhwc_fwd_tile_stats: null pointer");
     const int ts = conv_fwd_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
     STMI_REQUIRE(ts > 0, "conv2d_nhwc_fwd_tile_stats: this geometry produces no tile statistics "
@@ -296,6 +297,7 @@ int stmi_conv2d_transpose_nhwc_fwd_tile_stats(const void* x, const void* w_packe
                                               int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype,
                                               void* stream) {
     if (check_conv("conv2d_transpose_nhwc_fwd_tile_stats", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x && w_packed_dgrad && y && tile_stats, "conv2d_transpose_nhwc_fwd_tile_stats: null pointer");
     const int ts = conv_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
     STMI_REQUIRE(ts > 0, "conv2d_transpose_nhwc_fwd_tile_stats: this geometry produces no tile statistics "

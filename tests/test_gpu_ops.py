@@ -691,6 +691,41 @@ def test_adam_and_step_begin_on_odd_and_unaligned_buffers(cuda):
     assert big[0].item() == 1.0
 
 
+def test_tile_statistics_entries_say_what_they_cannot_do(cuda):
+    """The tile-statistics forms of the convolutions: the query returns 0 for a geometry whose kernel leaves none,
+    the launch then fails with the library's message; statistics of a two-rows-per-tile geometry come from the
+    plain convolution only; an empty batch is a no-op."""
+    from stmi import ops, lib
+    st = torch.cuda.current_stream().cuda_stream
+    # a transposed convolution the up-sampling kernel is not built for (48 output channels)
+    assert ops.conv_transpose_tile_stats_tiles((1, 8, 8, 64), (3, 3, 48, 64), 2, torch.bfloat16) == 0
+    x = torch.zeros((1, 8, 8, 64), device=cuda, dtype=torch.bfloat16)
+    wp = torch.zeros(ops.packed_elems(3, 3, 48, 64, ops.PACK_DGRAD), device=cuda, dtype=torch.bfloat16)
+    y = torch.empty((1, 16, 16, 48), device=cuda, dtype=torch.bfloat16)
+    ts = torch.zeros(64, device=cuda)
+    with pytest.raises(lib.StmiError, match='no tile statistics'):
+        lib.call('stmi_conv2d_transpose_nhwc_fwd_tile_stats', x.data_ptr(), wp.data_ptr(), y.data_ptr(), ts.data_ptr(),
+                 1, 8, 8, 64, 48, 3, 3, 2, lib.BF16, st)
+    # the 3-channel kernel leaves statistics for the (9, 32) layer only
+    assert ops.conv_rgb_tile_stats_tiles(16, 16, 64, 3) == 0 and ops.conv_rgb_tile_stats_tiles(16, 40, 32, 9) == 4
+    # a persistent-statistics geometry in bf16 (two rows per tile): ReLU with the statistics is refused
+    shape = (1, 270, 480, 128)
+    n_ts = ops.conv_tile_stats_tiles(shape, (3, 3, 128, 128), 1, torch.bfloat16)
+    assert n_ts == 2 * 68 * 15 and ops.conv_tile_stats_free(shape, (3, 3, 128, 128), 1, torch.bfloat16)
+    xb = torch.zeros(shape, device=cuda, dtype=torch.bfloat16)
+    wq = torch.zeros(ops.packed_elems(3, 3, 128, 128, ops.PACK_FWD), device=cuda, dtype=torch.bfloat16)
+    yb = torch.empty(shape, device=cuda, dtype=torch.bfloat16)
+    rows = torch.zeros((1, n_ts, 4, 128), device=cuda)
+    with pytest.raises(lib.StmiError, match='plain convolution'):
+        lib.call('stmi_conv2d_nhwc_fwd_tile_stats', xb.data_ptr(), wq.data_ptr(), None, yb.data_ptr(), None,
+                 rows.data_ptr(), 1, 270, 480, 128, 128, 3, 3, 1, 1, lib.BF16, st)
+    # empty batches
+    for entry, args in (('stmi_conv2d_nhwc_fwd_tile_stats', (None, None, None, None, None, None, 0, 8, 8, 128, 128, 3, 3, 1, 0)),
+                        ('stmi_conv2d_transpose_nhwc_fwd_tile_stats', (None, None, None, None, 0, 8, 8, 64, 32, 3, 3, 2)),
+                        ('stmi_conv2d_rgb_nhwc_fwd_tile_stats', (None, 1.0, None, None, None, None, 0, 8, 8, 32, 9))):
+        lib.call(entry, *args, lib.BF16, st)
+
+
 def test_error_reporting(cuda):
     from stmi import lib, ops
     x = torch.zeros((1, 4, 4, 3), device=cuda)
