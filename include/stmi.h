@@ -60,6 +60,9 @@ int stmi_device_arch(char* buf, int buflen);
 /* Profiling aid: the name a profiler shows for the kernel instantiation that this thread's
  * most recent convolution forward / backward-data call launched (empty before the first). */
 int stmi_last_conv_kernel(char* buf, int buflen);
+/* The same for this thread's most recent weight-gradient / Gram call: "wgrad_glds_kernel" (LDS-DMA operands,
+ * channel counts that are multiples of 64 bytes) or "wgrad_kernel" (register-staged, any channel count). */
+int stmi_last_wgrad_kernel(char* buf, int buflen);
 
 /* ---- weight packing ---------------------------------------------------- */
 /* Weights live as fp32 HWIO [kh,kw,ci,co] (the layout of the reference's
@@ -171,9 +174,13 @@ int stmi_conv2d_nhwc_dgrad_in_sums(const void* dy, const void* w_packed_dgrad, v
                                    int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                    int dtype, void* stream);
 /* Gradient w.r.t. W (Conv2DBackpropFilter): dw fp32 [kh,kw,ci,co].  accumulate == 0: dw is
- * overwritten (zeroed here first); accumulate != 0: the gradient is ADDED to dw, which the
- * caller has zeroed (a trainer clears its whole flat gradient buffer once per step). */
-int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw,
+ * overwritten; accumulate != 0: the gradient is ADDED to what dw holds.
+ * The sum over pixels is cut into slices that run on different blocks; the slices' partial results go to
+ * planes of `ws` (fp32, 16-byte aligned, stmi_conv2d_wgrad_ws_floats(...) floats; may be NULL when that is 0)
+ * and are added up in slice order by a second launch of the same call: no float atomics, the result is
+ * bit-reproducible from run to run. */
+long stmi_conv2d_wgrad_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, float* ws,
                            int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                            int accumulate, int dtype, void* stream);
 
@@ -199,8 +206,9 @@ int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, v
                                      const void* addend,
                                      int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                      int dtype, void* stream);
-/* dw fp32 [kh,kw,co,ci]; accumulate as above. */
-int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
+/* dw fp32 [kh,kw,co,ci]; accumulate and ws (stmi_conv2d_transpose_wgrad_ws_floats floats) as above. */
+long stmi_conv2d_transpose_wgrad_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, float* ws,
                                      int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                      int accumulate, int dtype, void* stream);
 
@@ -213,14 +221,18 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw,
  *          scratch of stmi_instance_norm_ws_floats floats (per-block partial sums).
  * apply  : y = act(scale*xhat + shift) [+ residual]; optional fp32 copy y_f32.
  * bwd    : from dy (gradient w.r.t. y) to dx, and ADDS the parameter gradients
- *          into dscale[c], dshift[c] (fp32).  The activation gradient is
- *          recomputed from x, so y is not needed. */
+ *          into dscale[c], dshift[c] (fp32; both NULL: not computed here, see
+ *          stmi_instance_norm_param_grads).  The activation gradient is
+ *          recomputed from x, so y is not needed.
+ * Nothing in these passes uses float atomics: results are bit-reproducible, and a sample's
+ * result does not depend on the batch it is part of. */
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
 int stmi_instance_norm_nhwc_stats(const void* x, float* ws, float* stats, float eps,
                                   int n, int h, int w, int c, int dtype, void* stream);
 /* stats + apply as one call of two launches: the apply blocks fold the statistics pass's partial sums
  * themselves (no separate finalize launch); stats[n,c,2] is written as by stmi_instance_norm_nhwc_stats
- * (same values up to the order of a few fp32 additions). */
+ * (same values up to the order of a few fp32 additions).  y must not alias x (the apply blocks read x's
+ * first pixel, the statistics' shift, while others already write y). */
 int stmi_instance_norm_nhwc_fwd(const void* x, float* ws, float* stats, float eps,
                                 const float* scale, const float* shift, const void* residual,
                                 void* y, float* y_f32, int act, int n, int h, int w, int c,
@@ -261,6 +273,16 @@ int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float*
                                      void* dx, float* dscale, float* dshift, const float* rows, int nrows,
                                      int act, int n, int h, int w, int c, int dtype, void* stream);
 
+/* The parameter gradients of the norm from the partial rows of its backward reduction, as a launch of its
+ * own (a trainer runs it beside the data-gradient chain): dshift[c] = sum over samples and rows of
+ * rows[.., 0, c], dscale[c] = of rows[.., 1, c], in one fixed order; accumulate != 0 adds to what they hold.
+ * rows: fp32 [n, nrows, 2, c] -- what stmi_conv2d_nhwc_dgrad_in_sums left, or the first n * nrows * 2 * c
+ * floats of the workspace stmi_instance_norm_nhwc_bwd used, nrows = stmi_instance_norm_bwd_rows_count(...)
+ * (the reduction pass's rows per sample for that geometry). */
+int stmi_instance_norm_bwd_rows_count(int n, int h, int w, int c, int dtype);
+int stmi_instance_norm_param_grads(const float* rows, int nrows, int n, int c, float* dscale, float* dshift,
+                                   int accumulate, void* stream);
+
 /* ---- VGG pieces -------------------------------------------------------- */
 /* x*255/2 - mean                                    (vgg.py:11-17)
  * x fp32 [count/c, c] -> y in dtype; y = x*scale - mean[c]. */
@@ -277,11 +299,12 @@ int stmi_maxpool2x2_same_bwd(const void* x, const void* dy, void* dx, int n, int
 
 /* ---- Gram matrix ------------------------------------------------------- */
 /* tf.linalg.einsum('bijc,bijd->bcd', F, F) / (H*W)   (model_utilities.py:380-384)
- * f [n,h,w,c] -> g fp32 [n,c,c], overwritten. */
-int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream);
-/* The same, ADDED into g (which the caller cleared, e.g. with stmi_zero_multi): saves the launch that
- * clears g. */
-int stmi_gram_nhwc_fwd_add(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream);
+ * f [n,h,w,c] -> g fp32 [n,c,c], overwritten.  ws: workspace of stmi_gram_ws_floats(...) floats for the
+ * partial sums of the pixel slices (as at stmi_conv2d_nhwc_wgrad; NULL when the query returns 0). */
+long stmi_gram_ws_floats(int n, int h, int w, int c, int dtype);
+int stmi_gram_nhwc_fwd(const void* f, float* g, float* ws, int n, int h, int w, int c, int dtype, void* stream);
+/* The same, ADDED into what g holds. */
+int stmi_gram_nhwc_fwd_add(const void* f, float* g, float* ws, int n, int h, int w, int c, int dtype, void* stream);
 /* df[p][c] (+)= sum_d F[p][d] * S[b][c][d], S = (dG + dG^T)/(H*W) in dtype, in the
  * zero-padded K-contiguous layout stmi_gram_mse_fwd_bwd writes
  * (stmi_gram_packed_elems elements).  accumulate != 0 adds into df.  c % 8 == 0. */
@@ -290,20 +313,31 @@ int stmi_gram_nhwc_bwd(const void* f, const void* s, void* df, int accumulate,
                        int n, int h, int w, int c, int dtype, void* stream);
 
 /* ---- losses ------------------------------------------------------------ */
-/* tf.reduce_mean((a-b)**2) terms of sum_mse          (model_utilities.py:387-388)
- * All three ADD loss_scale * sum((a-b)^2) into loss[0] (fp32, device) and emit
- * grad_scale * (a-b).
+/* A loss call leaves its term as PARTIAL SUMS, one per block of its launch, in a "loss slot": a caller-owned
+ * fp32 buffer of STMI_LOSS_SLOT_FLOATS floats, 16-byte aligned, which the call overwrites entirely (unused
+ * entries are cleared).  stmi_loss_slots_sum then adds the slots of each term up in a fixed order:
+ *   out[t] = sum over the slots first[t] .. first[t+1]-1   for t in [0, nterms)
+ * (`first`: HOST array of nterms + 1 slot indices into `slots`, read during the call; nterms <=
+ * STMI_LOSS_TERMS_MAX).  No float atomics: a loss value is bit-reproducible from run to run.  A step's slots can
+ * be summed by ONE launch, off the critical path, once all loss kernels of the step have been issued.
+ *
+ * tf.reduce_mean((a-b)**2) terms of sum_mse          (model_utilities.py:387-388)
+ * The slot receives loss_scale * sum((a-b)^2); grad (may be NULL for stmi_mse_fwd_bwd) = grad_scale * (a-b).
  * gram form: g fp32 [n,c,c], target fp32 [c,c] broadcast over n; s_out in dtype,
  * stmi_gram_packed_elems(n,c) elements. */
-int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* loss,
+#define STMI_LOSS_SLOT_FLOATS 1024
+#define STMI_LOSS_TERMS_MAX 8
+int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* slot,
                           float loss_scale, float grad_scale, int n, int c, int dtype, void* stream);
-int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* loss,
+int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* slot,
                      float loss_scale, float grad_scale, long count, int dtype, void* stream);
 /* total_variation_loss                               (model_utilities.py:369-377)
- * img fp32 [n,h,w,c]; loss[0] += weight*(mean(dx^2)+mean(dy^2)); grad (dtype) =
+ * img fp32 [n,h,w,c]; the slot receives weight*(mean(dx^2)+mean(dy^2)); grad (dtype) =
  * weight * d/d img, overwritten. */
-int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight,
+int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* slot, float weight,
                          int n, int h, int w, int c, int dtype, void* stream);
+/* add_n over the terms of sum_mse / total_loss      (model_utilities.py:387-399) */
+int stmi_loss_slots_sum(const float* slots, const int* first, int nterms, float* out, void* stream);
 
 /* ---- step begin -------------------------------------------------------- */
 /* Clears up to STMI_ZERO_MULTI_MAX fp32 buffers (ptrs[i], counts[i] floats) in ONE launch and, when

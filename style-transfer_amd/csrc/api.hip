@@ -20,6 +20,18 @@ int check_hip(hipError_t e, const char* what) {
     return STMI_ERR_HIP;
 }
 
+int ensure_dynamic_lds(const void* fn, int bytes, const char* what, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0;   // beyond 64 devices: set on every launch
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return STMI_OK;
+    rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+    if (rc) return rc;
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return STMI_OK;
+}
+
 // implemented in the kernel translation units
 const char* last_conv_kernel();
 int pack_weights_impl(const float*, void*, int, int, int, int, int, int, hipStream_t);
@@ -49,13 +61,20 @@ int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, 
 int conv_to3_supported(int k, int ci, int dtype);
 int conv_to3_impl(const void* x, const void* wq, const void* addend, void* y, int n, int h, int w, int ci, int k,
                   int dtype, hipStream_t s);
-int conv_wgrad_impl(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh, int kw,
-                    int stride, int accumulate, int dtype, hipStream_t s);
-int gram_fwd_impl(const void* f, float* g, int n, int h, int w, int c, int dtype, hipStream_t s, int accumulate);
+const char* last_wgrad_kernel();
+int conv_wgrad_impl(const void* x, const void* dy, float* dw, float* ws, int n, int h, int w, int ci, int co, int kh,
+                    int kw, int stride, int accumulate, int dtype, hipStream_t s);
+long conv_wgrad_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int gram_fwd_impl(const void* f, float* g, float* ws, int n, int h, int w, int c, int dtype, hipStream_t s,
+                  int accumulate);
+long gram_ws_floats(int n, int h, int w, int c, int dtype);
 int zero_multi_impl(float* const* ptrs, const long* counts, int n, int* step, hipStream_t s);
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
 long in_ws_floats(int n, int h, int w, int c);
+int in_param_grads_impl(const float* rows, int nrows, int n, int c, float* dscale, float* dshift, int accumulate,
+                        hipStream_t s);
+int in_bwd_rows_count(int n, int h, int w, int c, int dtype);
 int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
                   hipStream_t s);
 int in_fwd_impl(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
@@ -78,6 +97,7 @@ int pool_bwd_impl(const void*, const void*, void*, int, int, int, int, int, hipS
 int mse_impl(const void*, const void*, void*, float*, float, float, long, int, hipStream_t);
 int gram_mse_impl(const float*, const float*, void*, float*, float, float, int, int, int, hipStream_t);
 int tv_impl(const float*, void*, float*, float, int, int, int, int, int, hipStream_t);
+int loss_slots_sum_impl(const float* slots, const int* first, int nterms, float* out, hipStream_t s);
 int adam_impl(float*, const float*, float*, float*, long, float, float, float, float, float, int*, int, hipStream_t);
 
 static int check_dtype(int dtype) {
@@ -258,6 +278,7 @@ int stmi_conv2d_nhwc_dgrad_in_sums(const void* dy, const void* w_packed_dgrad, v
                                    const float* bn_scale, const float* bn_shift, int bn_act, float* rows, int n, int h,
                                    int w, int ci, int co, int kh, int kw, int stride, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_dgrad_in_sums", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(dy && w_packed_dgrad && dx && bn_x && bn_stats && bn_scale && bn_shift && rows,
                  "conv2d_nhwc_dgrad_in_sums: null pointer");
     STMI_REQUIRE(bn_act >= STMI_ACT_NONE && bn_act <= STMI_ACT_SIGMOID, "conv2d_nhwc_dgrad_in_sums: bad activation %d", bn_act);
@@ -271,11 +292,23 @@ int stmi_conv2d_nhwc_dgrad_in_sums(const void* dy, const void* w_packed_dgrad, v
                            S(stream), &bn);
 }
 
-int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co, int kh,
-                           int kw, int stride, int accumulate, int dtype, void* stream) {
+int stmi_last_wgrad_kernel(char* buf, int buflen) {
+    STMI_REQUIRE(buf && buflen > 0, "last_wgrad_kernel: bad arguments");
+    snprintf(buf, buflen, "%s", last_wgrad_kernel());
+    return STMI_OK;
+}
+
+long stmi_conv2d_wgrad_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || kh > 9 || kw > 9) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_wgrad_ws_floats(n, h, w, ci, co, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_nhwc_wgrad(const void* x, const void* dy, float* dw, float* ws, int n, int h, int w, int ci, int co,
+                           int kh, int kw, int stride, int accumulate, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && dw, "conv2d_nhwc_wgrad: null pointer");
-    return conv_wgrad_impl(x, dy, dw, n, h, w, ci, co, kh, kw, stride, accumulate, dtype, S(stream));
+    return conv_wgrad_impl(x, dy, dw, ws, n, h, w, ci, co, kh, kw, stride, accumulate, dtype, S(stream));
 }
 
 // A transposed conv x[n,h,w,ci] -> y[n,sh,sw,co] with W[kh,kw,co,ci] is the backward-data of the
@@ -314,11 +347,17 @@ int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, v
     return conv_fwd_impl(dy, w_packed_fwd, nullptr, dx, nullptr, addend, n, h * stride, w * stride, co, ci, kh, kw, stride, 0, dtype, S(stream));
 }
 
-int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, int n, int h, int w, int ci, int co,
-                                     int kh, int kw, int stride, int accumulate, int dtype, void* stream) {
+long stmi_conv2d_transpose_wgrad_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || kh > 9 || kw > 9) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_wgrad_ws_floats(n, h * stride, w * stride, co, ci, kh, kw, stride, dtype);
+}
+
+int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, float* ws, int n, int h, int w, int ci,
+                                     int co, int kh, int kw, int stride, int accumulate, int dtype, void* stream) {
     if (check_conv("conv2d_transpose_nhwc_wgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && dw, "conv2d_transpose_nhwc_wgrad: null pointer");
-    return conv_wgrad_impl(dy, x, dw, n, h * stride, w * stride, co, ci, kh, kw, stride, accumulate, dtype, S(stream));
+    return conv_wgrad_impl(dy, x, dw, ws, n, h * stride, w * stride, co, ci, kh, kw, stride, accumulate, dtype, S(stream));
 }
 
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c) { return in_ws_floats(n, h, w, c); }
@@ -356,6 +395,8 @@ int stmi_instance_norm_nhwc_fwd(const void* x, float* ws, float* stats, float ep
     STMI_REQUIRE(x && ws && stats && scale && shift && y && n >= 0 && h > 0 && w > 0 && c > 0,
                  "instance_norm_nhwc_fwd: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_fwd: bad activation %d", act);
+    STMI_REQUIRE(y != x, "instance_norm_nhwc_fwd: y must not alias x (every apply block reads the statistics' shift "
+                 "from x's first pixel while others already write y); stmi_instance_norm_nhwc_stats + _apply may run in place");
     if (n == 0) return STMI_OK;
     return in_fwd_impl(x, ws, stats, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype, S(stream));
 }
@@ -377,8 +418,8 @@ int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stat
                                 int act, int n, int h, int w, int c, int dtype, void* stream) {
     (void)eps;  // 1/sqrt(var+eps) is taken from `stats`
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(x && dy && stats && scale && shift && dx && dscale && dshift && ws && n >= 0 && h > 0 && w > 0 && c > 0,
-                 "instance_norm_nhwc_bwd: bad arguments");
+    STMI_REQUIRE(x && dy && stats && scale && shift && dx && ws && n >= 0 && h > 0 && w > 0 && c > 0 &&
+                 (dscale == nullptr) == (dshift == nullptr), "instance_norm_nhwc_bwd: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd: bad activation %d", act);
     if (n == 0) return STMI_OK;
     return in_bwd_impl(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, dtype, S(stream));
@@ -388,11 +429,23 @@ int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float*
                                      const float* shift, void* dx, float* dscale, float* dshift, const float* rows,
                                      int nrows, int act, int n, int h, int w, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(x && dy && stats && scale && shift && dx && dscale && dshift && rows && nrows > 0 && n >= 0 && h > 0 &&
-                 w > 0 && c > 0, "instance_norm_nhwc_bwd_rows: bad arguments");
+    STMI_REQUIRE(x && dy && stats && scale && shift && dx && rows && nrows > 0 && n >= 0 && h > 0 && w > 0 && c > 0 &&
+                 (dscale == nullptr) == (dshift == nullptr), "instance_norm_nhwc_bwd_rows: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd_rows: bad activation %d", act);
     if (n == 0) return STMI_OK;
     return in_bwd_rows_impl(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_bwd_rows_count(int n, int h, int w, int c, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
+    return in_bwd_rows_count(n, h, w, c, dtype);
+}
+
+int stmi_instance_norm_param_grads(const float* rows, int nrows, int n, int c, float* dscale, float* dshift,
+                                   int accumulate, void* stream) {
+    STMI_REQUIRE(rows && dscale && dshift && nrows > 0 && n >= 0 && c > 0, "instance_norm_param_grads: bad arguments");
+    if (n == 0) return STMI_OK;
+    return in_param_grads_impl(rows, nrows, n, c, dscale, dshift, accumulate, S(stream));
 }
 
 int stmi_scale_shift(const float* x, const float* mean, void* y, float scale, long count, int c, int dtype,
@@ -418,18 +471,23 @@ int stmi_maxpool2x2_same_bwd(const void* x, const void* dy, void* dx, int n, int
     return pool_bwd_impl(x, dy, dx, n, h, w, c, dtype, S(stream));
 }
 
-int stmi_gram_nhwc_fwd(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream) {
+long stmi_gram_ws_floats(int n, int h, int w, int c, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
+    return gram_ws_floats(n, h, w, c, dtype);
+}
+
+int stmi_gram_nhwc_fwd(const void* f, float* g, float* ws, int n, int h, int w, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(f && g && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_fwd: bad arguments");
     if (n == 0) return STMI_OK;
-    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream), 0);
+    return gram_fwd_impl(f, g, ws, n, h, w, c, dtype, S(stream), 0);
 }
 
-int stmi_gram_nhwc_fwd_add(const void* f, float* g, int n, int h, int w, int c, int dtype, void* stream) {
+int stmi_gram_nhwc_fwd_add(const void* f, float* g, float* ws, int n, int h, int w, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(f && g && n >= 0 && h > 0 && w > 0 && c > 0, "gram_nhwc_fwd_add: bad arguments");
     if (n == 0) return STMI_OK;
-    return gram_fwd_impl(f, g, n, h, w, c, dtype, S(stream), 1);
+    return gram_fwd_impl(f, g, ws, n, h, w, c, dtype, S(stream), 1);
 }
 
 int stmi_zero_multi(float* const* ptrs, const long* counts, int n, int* step_dev, void* stream) {
@@ -452,28 +510,37 @@ long stmi_gram_packed_elems(int n, int c) {
     return (long)n * g.rows_pad * g.kpad;
 }
 
-int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* loss, float loss_scale,
+int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, float* slot, float loss_scale,
                           float grad_scale, int n, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(g && target && s_out && loss && n >= 0 && c > 0 && c % 8 == 0, "gram_mse_fwd_bwd: bad arguments (c=%d)", c);
+    STMI_REQUIRE(g && target && s_out && slot && n >= 0 && c > 0 && c % 8 == 0, "gram_mse_fwd_bwd: bad arguments (c=%d)", c);
     if (n == 0) return STMI_OK;
-    return gram_mse_impl(g, target, s_out, loss, loss_scale, grad_scale, n, c, dtype, S(stream));
+    return gram_mse_impl(g, target, s_out, slot, loss_scale, grad_scale, n, c, dtype, S(stream));
 }
 
-int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* loss, float loss_scale, float grad_scale,
+int stmi_mse_fwd_bwd(const void* a, const void* b, void* grad, float* slot, float loss_scale, float grad_scale,
                      long count, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(a && b && loss && count >= 0, "mse_fwd_bwd: bad arguments");
+    STMI_REQUIRE(a && b && slot && count >= 0, "mse_fwd_bwd: bad arguments");
     if (count == 0) return STMI_OK;
-    return mse_impl(a, b, grad, loss, loss_scale, grad_scale, count, dtype, S(stream));
+    return mse_impl(a, b, grad, slot, loss_scale, grad_scale, count, dtype, S(stream));
 }
 
-int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* loss, float weight, int n, int h, int w, int c,
+int stmi_tv_loss_fwd_bwd(const float* img, void* grad, float* slot, float weight, int n, int h, int w, int c,
                          int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
-    STMI_REQUIRE(img && grad && loss && n >= 0 && h > 0 && w > 0 && c > 0, "tv_loss_fwd_bwd: bad arguments");
+    STMI_REQUIRE(img && grad && slot && n >= 0 && h > 0 && w > 0 && c > 0, "tv_loss_fwd_bwd: bad arguments");
     if (n == 0) return STMI_OK;
-    return tv_impl(img, grad, loss, weight, n, h, w, c, dtype, S(stream));
+    return tv_impl(img, grad, slot, weight, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_loss_slots_sum(const float* slots, const int* first, int nterms, float* out, void* stream) {
+    STMI_REQUIRE(slots && first && out && nterms >= 1 && nterms <= STMI_LOSS_TERMS_MAX,
+                 "loss_slots_sum: bad arguments (1 .. %d terms)", STMI_LOSS_TERMS_MAX);
+    for (int t = 0; t < nterms; t++)
+        STMI_REQUIRE(first[t] >= 0 && first[t] <= first[t + 1], "loss_slots_sum: first[] must not decrease");
+    STMI_REQUIRE((((uintptr_t)slots) & 15) == 0, "loss_slots_sum: slots must be 16-byte aligned");
+    return loss_slots_sum_impl(slots, first, nterms, out, S(stream));
 }
 
 int stmi_adam_tf1(float* p, const float* g, float* m, float* v, long count, float lr, float beta1, float beta2,

@@ -44,6 +44,19 @@ int check_hip(hipError_t e, const char* what);
         }                                            \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device: the attribute belongs to a
+// device's copy of the code object, so a process that uses several GPUs sets it on each.  `done` is a static
+// of the call site (one per kernel instantiation) with one bit per device ordinal; the call is idempotent, so
+// host threads racing here both succeed.
+int ensure_dynamic_lds(const void* fn, int bytes, const char* what, std::atomic<unsigned long long>& done);
+
+#define STMI_DYN_LDS(kernel, bytes, what)                                               \
+    do {                                                                                \
+        static std::atomic<unsigned long long> done_{0};                                \
+        int rc_ = ::stmi::ensure_dynamic_lds((const void*)kernel, bytes, what, done_);  \
+        if (rc_) return rc_;                                                            \
+    } while (0)
+
 #define STMI_LAUNCH_CHECK(name)                                         \
     do {                                                                \
         int _rc = ::stmi::check_hip(hipGetLastError(), name);           \

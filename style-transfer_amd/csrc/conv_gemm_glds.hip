@@ -258,14 +258,7 @@ template <typename T, int TC, int TP, int WC, int WP, int NS>
 static int launch_one(const ConvGemmParams& p, hipStream_t s) {
     constexpr int BLK_CO = 16 * TC * WC, BLK_PIX = 16 * TP * WP;
     constexpr size_t kLds = (size_t)NS * (BLK_CO + BLK_PIX) * 128;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_gemm_glds_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_gemm_glds_kernel<T, TC, TP, WC, WP, NS>), (int)kLds, "hipFuncSetAttribute(conv_gemm_glds_kernel)");
     const bool batched = p.w_batch_stride != 0;
     const long Mz = batched ? (long)p.Hs * p.Ws : (long)p.N * p.Hs * p.Ws;
     if (Mz <= 0) return STMI_OK;

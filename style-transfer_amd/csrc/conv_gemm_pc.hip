@@ -266,14 +266,7 @@ template <typename T, int TC, int TP, int RB, int RING = kRing>
 static int launch_pc(const ConvGemmParams& p_in, hipStream_t s, char* name, int name_len, const char* tname) {
     ConvGemmParams p = p_in;
     constexpr size_t kLds = (size_t)RING * (32 * TC + 32 * TP) * RB;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_gemm_pc_kernel<T, TC, TP, RB, RING>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_gemm_pc_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_gemm_pc_kernel<T, TC, TP, RB, RING>), (int)kLds, "hipFuncSetAttribute(conv_gemm_pc_kernel)");
     if (name)
         snprintf(name, name_len, "void stmi::conv_gemm_pc_kernel<%s, %d, %d, %d, %d>(stmi::ConvGemmParams)", tname, TC, TP, RB, RING);
     const long tiles = p.nclasses > 0 ? pc_assign_tiles(p, 32 * TC, 32 * TP) : pc_tiles(p, 32 * TC, 32 * TP);

@@ -1013,14 +1013,7 @@ static int patch_blk_co(const ConvGemmParams& p, int dtype) {
 template <typename T, int TC, int PW, int NSW, bool ONE>
 static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * 4 * kPatchPieces * 8 * 128;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_kernel<T, TC, PW, NSW, ONE>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_patch_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_patch_kernel<T, TC, PW, NSW, ONE>), (int)kLds, "hipFuncSetAttribute(conv_patch_kernel)");
     const long tiles = patch_tiles(p, 32 * TC);
     if (tiles <= 0) return STMI_OK;
     ConvGemmParams q = p;
@@ -1061,16 +1054,18 @@ static int launch_patch_w(const ConvGemmParams& p, hipStream_t s) {
     }
 }
 
-// Compute units of the current device (the persistent kernel's grid), looked up once per process.
+// Compute units of the current device (the persistent kernel's grid), looked up once per device.
 static int device_cus() {
-    static std::atomic<int> cus{0};
-    int v = cus.load(std::memory_order_acquire);
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cus[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int v = cus[dev].load(std::memory_order_acquire);
     if (v == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        v = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        v = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
         if (v < 8) v = 8;
-        cus.store(v, std::memory_order_release);
+        cus[dev].store(v, std::memory_order_release);
     }
     return v;
 }
@@ -1121,14 +1116,7 @@ static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
                                     : (size_t)16 * (TC >= 4 ? 2 : 4) * 2 * (32 * TC + 4) * 4;
     constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * kPatch + kStage;
     static_assert(kLds <= 160 * 1024, "operand buffers + staging rows exceed the CU's LDS");
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_patch_pers_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>), (int)kLds, "hipFuncSetAttribute(conv_patch_pers_kernel)");
     const long tiles = patch_tiles(p, 32 * TC);
     STMI_REQUIRE(tiles > 0 && tiles < (1L << 31), "conv: tile count out of range");
     ConvGemmParams q = p;

@@ -220,14 +220,7 @@ static int launch_rgb(const XT* x, float scale, const float* mean, const void* w
     constexpr int S_WAVES = 4 * 64 * (CO * (int)sizeof(T) + 16);   // the STATS epilogue's per-wave rows
     constexpr int S_NEED = STATS ? S_WAVES : S_BYTES;
     constexpr size_t kLds = (size_t)((W_BYTES + P_BYTES > S_NEED ? W_BYTES + P_BYTES : S_NEED) + 15) / 16 * 16;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_rgb_kernel<T, K, TC, XT, STATS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_rgb_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_rgb_kernel<T, K, TC, XT, STATS>), (int)kLds, "hipFuncSetAttribute(conv_rgb_kernel)");
     {
         char name[160];
         const char* tn = sizeof(T) == 2 ? "__bf16" : "float";

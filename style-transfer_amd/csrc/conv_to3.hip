@@ -160,14 +160,7 @@ static int launch_to3(const void* x, const void* wq, const void* addend, void* y
     constexpr int OPS = K * 32 * RB + (kTo3PH + K - 1) * COLS * RB;
     constexpr int TBYTES = kTo3PH * COLS * kTo3Stride * 4;
     constexpr size_t kLds = (size_t)((OPS > TBYTES ? OPS : TBYTES) + 15) / 16 * 16;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_to3_kernel<T, K, RB, COLS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_to3_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_to3_kernel<T, K, RB, COLS>), (int)kLds, "hipFuncSetAttribute(conv_to3_kernel)");
     {
         char name[160];
         const char* tn = sizeof(T) == 2 ? "__bf16" : "float";

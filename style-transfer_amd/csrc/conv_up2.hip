@@ -291,14 +291,7 @@ static int launch_up2(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kOperands = (size_t)kRing * 16 * COF * 128 + (size_t)NCH * 4 * kPatchPieces * 1024;
     constexpr size_t kStage = (size_t)4 * 64 * (16 * COF * sizeof(T) + 16);
     constexpr size_t kLds = kOperands > kStage ? kOperands : kStage;
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)conv_up2_kernel<T, NCH, COF, STATS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(conv_up2_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
+    STMI_DYN_LDS((conv_up2_kernel<T, NCH, COF, STATS>), (int)kLds, "hipFuncSetAttribute(conv_up2_kernel)");
     hipLaunchKernelGGL((conv_up2_kernel<T, NCH, COF, STATS>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
     STMI_LAUNCH_CHECK("conv_up2_kernel");
     return STMI_OK;

@@ -15,14 +15,27 @@ struct WgradParams {
     long tap_out_stride;
     long batch_out_stride;  // != 0: one output per sample (Gram)
     int pix_per_block;
-    int splits;
+    int splits;             // blocks that share one output tile, each with a slice of the pixels
     float alpha;
+    // The pixel slices of a tile are combined WITHOUT atomics, so that the sum has one fixed order:
+    // with splits > 1 slice s writes its partial tile (plain stores) to ws + s * out_elems at the offset the
+    // tile has in dw, and fold_partials adds the planes up in slice order.  splits == 1: the tile goes
+    // straight to dw (added to what dw holds when `accumulate`).
+    float* ws;
+    long out_elems;   // floats of the whole output (all samples, taps, tiles)
+    int accumulate;
     Tap taps[kMaxTaps];
 };
 
-// LDS-DMA variant with producer / consumer waves (conv_wgrad_glds.hip).  Returns true and
-// launches when the problem fits it (channel counts that are multiples of 128 bytes on both
-// operands); *rc receives the status.  The output must already hold the values to add to.
-bool try_launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s, int* rc);
+// How a launch cuts the pixels: the workspace it needs follows from it.
+struct WgPlan {
+    int splits, pix_per_block;
+};
+
+// LDS-DMA variant with producer / consumer waves (conv_wgrad_glds.hip).  wgrad_glds_plan returns false when
+// the problem does not fit it (channel counts that are not multiples of 64 bytes on both operands, unaligned
+// tensors); launch_wgrad_glds runs the plan that the caller stored in p.splits / p.pix_per_block.
+bool wgrad_glds_plan(const WgradParams& p, int dtype, WgPlan* plan);
+int launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s);
 
 }  // namespace stmi

@@ -16,8 +16,10 @@
 // bytes per 16 lanes) conflict-free.  The K order inside a 32-pixel group follows the
 // hardware transpose; it only has to agree between the two operands.
 //
-// The finished tile goes through LDS so that every wave adds whole 256-byte rows: float
-// atomics run at the memory side at about 1.3 TB/s, and only for contiguous rows.
+// The finished tile goes through LDS so that every wave stores whole 256-byte rows.  Blocks that
+// share a tile (each with a slice of the pixels) do not add into it: a slice writes its partial tile
+// to a plane of its own in the workspace and a fold kernel sums the planes in slice order, so the
+// result has one fixed summation order (float atomics would make it depend on the arrival order).
 #include "conv_wgrad.hpp"
 
 #include <stdlib.h>
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
         }
     }
 
-    // epilogue: tile -> LDS -> row-wise atomic adds
+    // epilogue: tile -> LDS -> whole rows, 16 bytes per lane
     constexpr int LD = TD + 4;
     float* stage_f = reinterpret_cast<float*>(lds);
     __syncthreads();
@@ -270,11 +272,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
                     stage_f[((wr * TWX + a) * 16 + 4 * g + u) * LD + (wcn * TWD + b) * 16 + i] = acc[a][b][u];
     }
     __syncthreads();
-    if (nsteps == 0) return;
-    float* out = p.dw + (long)sample * p.batch_out_stride + (long)tap_i * p.tap_out_stride + (long)r0 * p.Co + c0;
-    const int col = tid % TD;
-    for (int row = tid / TD; row < TE; row += kThreads / TD)
-        atomicAdd(out + (long)row * p.Co + col, stage_f[row * LD + col] * p.alpha);
+    // a slice of a shared tile writes its plane of the workspace; a tile with one slice goes to dw itself
+    float* out = (p.splits > 1 ? p.ws + (long)split * p.out_elems : p.dw) + (long)sample * p.batch_out_stride +
+                 (long)tap_i * p.tap_out_stride + (long)r0 * p.Co + c0;
+    const bool add = p.splits == 1 && p.accumulate;
+    constexpr int QPR = TD / 4;   // 16-byte pieces per tile row
+    const int q = tid % QPR;
+    for (int row = tid / QPR; row < TE; row += kThreads / QPR) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage_f + row * LD + 4 * q) * p.alpha;
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (long)row * p.Co + 4 * q);
+        if (add) v += *dst;
+        *dst = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -289,31 +298,20 @@ static int row_bytes(int channels, int dtype) {
 static bool wg_eligible(const WgradParams& p, int dtype) {
     if (p.cdiv != 0 || p.klen != p.Ci || row_bytes(p.Ci, dtype) == 0 || row_bytes(p.Co, dtype) == 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
-    if ((((uintptr_t)p.x | (uintptr_t)p.dy) & 15) != 0) return false;
+    if ((((uintptr_t)p.x | (uintptr_t)p.dy | (uintptr_t)p.dw | (uintptr_t)p.ws) & 15) != 0) return false;
+    if (p.out_elems % 4 != 0) return false;   // planes of the workspace stay 16-byte aligned
     return true;
 }
 
-template <typename T, int XB, int DB>
-static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
-    constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);
-    constexpr size_t kLds = (size_t)kRing * kStepPix * (XB + DB);
-    static std::atomic<bool> attr_set{false};  // the call is idempotent: two host threads racing here both succeed
-    if (!attr_set.load(std::memory_order_acquire)) {
-        int rc = check_hip(hipFuncSetAttribute((const void*)wgrad_glds_kernel<T, XB, DB>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds),
-                           "hipFuncSetAttribute(wgrad_glds_kernel)");
-        if (rc) return rc;
-        attr_set.store(true, std::memory_order_release);
-    }
-    WgradParams p = p_in;
+// pixel slices per tile for TE x TD tiles
+static WgPlan plan_for(const WgradParams& p, int te, int td) {
     const bool batched = p.batch_out_stride != 0;
     const long pix_total = batched ? (long)p.Ho * p.Wo : (long)p.N * p.Ho * p.Wo;
-    const long tiles = (long)p.ntaps * (p.klen / TE) * (p.Co / TD);
+    const long tiles = (long)p.ntaps * (p.klen / te) * (p.Co / td);
     const long groups = tiles * (batched ? p.N : 1);
-    // about one block per CU for 64 x 64 tiles (every extra slice of the pixels costs a tile of
-    // atomics), two for the smaller tiles whose atomics are cheap and whose steps are short
+    // about one block per CU for 64 x 64 tiles, two for the smaller tiles whose steps are short
     const int tb = STMI_ENV_INT("STMI_WG_BLOCKS", 0);
-    const long target = tb > 0 ? tb : (TE * TD >= 64 * 64 ? 256 : 512);
+    const long target = tb > 0 ? tb : (te * td >= 64 * 64 ? 256 : 512);
     long splits = target / groups;
     const long max_splits = (pix_total + 2 * kStepPix - 1) / (2 * kStepPix);  // at least two steps per block
     if (splits > max_splits) splits = max_splits;
@@ -321,23 +319,47 @@ static int launch_wg_glds(const WgradParams& p_in, hipStream_t s) {
     long ppb = (pix_total + splits - 1) / splits;
     ppb = (ppb + kStepPix - 1) / kStepPix * kStepPix;
     splits = (pix_total + ppb - 1) / ppb;
-    p.pix_per_block = (int)ppb;
-    p.splits = (int)splits;
-    const long blocks = tiles * splits * (batched ? p.N : 1);
+    WgPlan plan;
+    plan.pix_per_block = (int)ppb;
+    plan.splits = (int)splits;
+    return plan;
+}
+
+static void tile_dims(const WgradParams& p, int dtype, int* te, int* td) {
+    const int es = dtype == STMI_BF16 ? 2 : 4;
+    *te = (dtype == STMI_BF16 ? row_bytes(p.Ci, dtype) : 128) / es;
+    *td = (dtype == STMI_BF16 ? row_bytes(p.Co, dtype) : 128) / es;
+}
+
+bool wgrad_glds_plan(const WgradParams& p, int dtype, WgPlan* plan) {
+    if (!wg_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_WG_GLDS")) return false;
+    int te, td;
+    tile_dims(p, dtype, &te, &td);
+    *plan = plan_for(p, te, td);
+    return true;
+}
+
+template <typename T, int XB, int DB>
+static int launch_wg_glds(const WgradParams& p, hipStream_t s) {
+    constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);
+    constexpr size_t kLds = (size_t)kRing * kStepPix * (XB + DB);
+    STMI_DYN_LDS((wgrad_glds_kernel<T, XB, DB>), (int)kLds, "hipFuncSetAttribute(wgrad_glds_kernel)");
+    const bool batched = p.batch_out_stride != 0;
+    const long tiles = (long)p.ntaps * (p.klen / TE) * (p.Co / TD);
+    const long blocks = tiles * p.splits * (batched ? p.N : 1);
     STMI_REQUIRE(blocks < (1L << 31), "wgrad: grid too large");
+    STMI_REQUIRE(p.splits == 1 || p.ws, "wgrad: %d pixel slices per tile need the workspace", p.splits);
     dim3 grid((unsigned)blocks);
     hipLaunchKernelGGL((wgrad_glds_kernel<T, XB, DB>), grid, dim3(kThreads), kLds, s, p);
     STMI_LAUNCH_CHECK("wgrad_glds_kernel");
     return STMI_OK;
 }
 
-bool try_launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s, int* rc) {
-    if (!wg_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_WG_GLDS")) return false;
+int launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s) {
     const int xb = row_bytes(p.Ci, dtype), db = row_bytes(p.Co, dtype);
-    if (dtype != STMI_BF16) *rc = launch_wg_glds<float, 128, 128>(p, s);
-    else if (xb == 128) *rc = db == 128 ? launch_wg_glds<bf16_t, 128, 128>(p, s) : launch_wg_glds<bf16_t, 128, 64>(p, s);
-    else *rc = db == 128 ? launch_wg_glds<bf16_t, 64, 128>(p, s) : launch_wg_glds<bf16_t, 64, 64>(p, s);
-    return true;
+    if (dtype != STMI_BF16) return launch_wg_glds<float, 128, 128>(p, s);
+    if (xb == 128) return db == 128 ? launch_wg_glds<bf16_t, 128, 128>(p, s) : launch_wg_glds<bf16_t, 128, 64>(p, s);
+    return db == 128 ? launch_wg_glds<bf16_t, 64, 128>(p, s) : launch_wg_glds<bf16_t, 64, 64>(p, s);
 }
 
 }  // namespace stmi

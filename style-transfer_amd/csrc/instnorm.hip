@@ -8,7 +8,8 @@
 //            conditioned; written to a workspace, no atomics, bit-reproducible
 //   finalize one block per sample folds the partials into per-channel constants
 //   apply    streams the tensor once more and writes the result
-// The only atomics are the per-channel parameter gradients (summed over samples).
+// No atomics: the per-channel parameter gradients (sums over samples and partial rows) are folded in a fixed
+// order by a small kernel of their own (in_param_grads_kernel).
 #include "common.hpp"
 
 namespace stmi {
@@ -473,27 +474,43 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
     block_combine<V>(s1, s2, red, ws + ((long)n * g.S + s) * 2 * g.C, g.C, CG, slots, active);
 }
 
+// Parameter gradients of an instance norm from the partial rows of its backward reduction ([n][nrows][2C]:
+// sum(g) in [0, C), sum(g * xhat) in [C, 2C)): dshift[c] (+)= sum over samples and rows of the first,
+// dscale[c] (+)= of the second.  A block owns 64 of the 2C columns; its four waves take every fourth row
+// (loads coalesced over the columns, independent, so in flight together) and their four sums are joined in
+// wave order: one fixed summation order whatever the launch looks like around it.
+__global__ __launch_bounds__(256) void in_param_grads_kernel(const float* __restrict__ rows, int total_rows, int C,
+                                                             float* dscale, float* dshift, int accumulate) {
+    __shared__ float part[4][64];
+    const int W = 2 * C, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < W) {
+#pragma unroll 8
+        for (int r = grp; r < total_rows; r += 4) acc += rows[(long)r * W + col];
+    }
+    part[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && col < W) {
+        const int l = threadIdx.x;
+        const float t = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+        float* dst = col < C ? dshift + col : dscale + (col - C);
+        *dst = accumulate ? *dst + t : t;
+    }
+}
+
 // backward pass 2 (of two): folds the partial rows of pass 1 itself, then
-// dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat)); block 0 of a sample adds the sample's share of the
-// parameter gradients (summed over samples by atomics, the only ones of the pass)
+// dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat))
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ ws, float* dscale, float* dshift,
-                                                           T* dx, int act, InGeom g) {
+                                                           const float* __restrict__ ws, T* dx, int act, InGeom g) {
     extern __shared__ float sh[];  // [2C] sums | [256] scratch
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     fold_rows_block(ws + (long)n * g.S * 2 * g.C, g.S, g.C, sh, sh + 2 * g.C);
-    if (blockIdx.x == 0) {
-        for (int c = tid; c < g.C; c += 256) {
-            atomicAdd(dshift + c, sh[c]);
-            atomicAdd(dscale + c, sh[g.C + c]);
-        }
-    }
     if (tid >= slots * CG) return;
     const int slot = tid / CG, cg = tid - slot * CG;
     const float inv = 1.f / (float)g.HW;
@@ -613,11 +630,16 @@ constexpr int kFoldMaxTiles = 32;  // longer tile rows get a finalize launch ins
 static inline size_t fold_shared_bytes(int c) { return (size_t)(4 * c + 256) * sizeof(float); }
 
 // src_kind: 0 statistics already in `stats`; 1 partial rows of the statistics pass in `src`; 2 tile sums in `src`
+// rows_s: src_kind 1 only -- the number of partial rows per sample the statistics launch wrote
 template <typename T>
 static int apply_typed(const void* x, float* stats, int src_kind, const float* src, int ts, float eps,
                        const float* scale, const float* shift, const void* residual, void* y, float* y_f32, int act,
-                       int n, int h, int w, int c, hipStream_t s) {
-    const InGeom g = make_geom<T>(n, h, w, c);
+                       int n, int h, int w, int c, hipStream_t s, int rows_s = 0) {
+    InGeom g = make_geom<T>(n, h, w, c);
+    if (src_kind == 1) {
+        STMI_REQUIRE(rows_s > 0 && rows_s <= kInFoldMaxRows, "instance norm: %d partial rows cannot be folded by the apply blocks", rows_s);
+        g.S = rows_s;   // the apply blocks fold exactly the rows the statistics launch wrote
+    }
     if (src_kind == 2 && ts > kFoldMaxTiles) {
         // the launch shape depends on the channel count only: a sample's statistics must not depend on its batch
         if (c % 8 == 0)
@@ -659,7 +681,20 @@ static int fwd_typed(const void* x, float* ws, float* stats, float eps, const fl
         STMI_LAUNCH_CHECK("in_stats_finalize_kernel");
         return apply_typed<T>(x, stats, 0, nullptr, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
     }
-    return apply_typed<T>(x, stats, 1, ws, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
+    return apply_typed<T>(x, stats, 1, ws, 0, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s, g.S);
+}
+
+int in_param_grads_impl(const float* rows, int nrows, int n, int c, float* dscale, float* dshift, int accumulate,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(in_param_grads_kernel, dim3((2 * c + 63) / 64), dim3(256), 0, s, rows, n * nrows, c, dscale,
+                       dshift, accumulate);
+    STMI_LAUNCH_CHECK("in_param_grads_kernel");
+    return STMI_OK;
+}
+
+// partial rows per sample the backward reduction pass leaves in its workspace for this geometry
+int in_bwd_rows_count(int n, int h, int w, int c, int dtype) {
+    return dtype == STMI_BF16 ? make_geom<bf16_t>(n, h, w, c).S : make_geom<float>(n, h, w, c).S;
 }
 
 template <typename T>
@@ -672,10 +707,10 @@ static int bwd_typed(const void* x, const void* dy, const float* stats, const fl
         hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, (const T*)dy, stats, scale, shift, ws, act, g);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
-                           s, (const T*)x, (const T*)dy, stats, scale, shift, (const float*)ws, dscale, dshift, (T*)dx,
-                           act, g);
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, (const float*)ws, (T*)dx, act, g);
     });
     STMI_LAUNCH_CHECK("in_bwd kernels");
+    if (dscale && dshift) return in_param_grads_impl(ws, g.S, n, c, dscale, dshift, 1, s);
     return STMI_OK;
 }
 
@@ -690,9 +725,10 @@ static int bwd_rows_typed(const void* x, const void* dy, const float* stats, con
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
-                           s, (const T*)x, (const T*)dy, stats, scale, shift, rows, dscale, dshift, (T*)dx, act, g);
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, rows, (T*)dx, act, g);
     });
     STMI_LAUNCH_CHECK("in_bwd_apply_kernel");
+    if (dscale && dshift) return in_param_grads_impl(rows, nrows, n, c, dscale, dshift, 1, s);
     return STMI_OK;
 }
 

@@ -181,7 +181,18 @@ int pool_bwd_impl(const void* x, const void* dy, void* dx, int n, int h, int w, 
 }
 
 // --------------------------------------------------------------------- losses
-// The loss kernels end in one atomic add per block on a single address: keep the grid small.
+// A loss kernel does not add its term into one scalar (float atomics: the sum would depend on the order in
+// which blocks finish).  Block b writes ITS partial sum to slot[b] of a "loss slot" of STMI_LOSS_SLOT_FLOATS
+// floats, block 0 clears the entries no block owns, and loss_slots_sum_kernel adds a term's slots up in a
+// fixed order.  Grids are capped at the slot length.
+constexpr int kSlot = STMI_LOSS_SLOT_FLOATS;
+
+__device__ __forceinline__ void slot_write(float* slot, float block_total) {
+    if (threadIdx.x == 0) slot[blockIdx.x] = block_total;
+    if (blockIdx.x == 0)
+        for (int i = gridDim.x + threadIdx.x; i < kSlot; i += blockDim.x) slot[i] = 0.f;
+}
+
 static inline int reduce_blocks(long work_items) {
     long b = (work_items + 2047) / 2048;
     if (b > 128) b = 128;
@@ -189,10 +200,10 @@ static inline int reduce_blocks(long work_items) {
     return (int)b;
 }
 
-// loss[0] += loss_scale * sum((a-b)^2); grad = grad_scale * (a-b)
+// slot[block] = loss_scale * sum((a-b)^2) over the block's elements; grad = grad_scale * (a-b)
 template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ grad,
-                                                  float* loss, float loss_scale, float grad_scale, long count) {
+                                                  float* slot, float loss_scale, float grad_scale, long count) {
     __shared__ float red[4];
     float acc = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
@@ -201,95 +212,129 @@ __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const
         if (grad) grad[i] = from_f32<T>(grad_scale * d);
     }
     const float tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
+    slot_write(slot, tot * loss_scale);
 }
 
-int mse_impl(const void* a, const void* b, void* grad, float* loss, float loss_scale, float grad_scale, long count,
+int mse_impl(const void* a, const void* b, void* grad, float* slot, float loss_scale, float grad_scale, long count,
              int dtype, hipStream_t s) {
     const dim3 grid(reduce_blocks(count));
     if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(mse_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)grad, loss, loss_scale, grad_scale, count);
+        hipLaunchKernelGGL(mse_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)grad, slot, loss_scale, grad_scale, count);
     else
-        hipLaunchKernelGGL(mse_kernel<float>, grid, dim3(256), 0, s, (const float*)a, (const float*)b, (float*)grad, loss, loss_scale, grad_scale, count);
+        hipLaunchKernelGGL(mse_kernel<float>, grid, dim3(256), 0, s, (const float*)a, (const float*)b, (float*)grad, slot, loss_scale, grad_scale, count);
     STMI_LAUNCH_CHECK("mse_kernel");
+    return STMI_OK;
+}
+
+// out[t] = sum of the slots first[t] .. first[t + 1] - 1, one block per term.  A slot is summed as 256 threads x
+// 4 consecutive entries, wave butterflies, then the four waves in order; the slots of a term are added in index
+// order: the order never depends on timing.
+struct SlotTerms {
+    int first[STMI_LOSS_TERMS_MAX + 1];
+};
+
+__global__ __launch_bounds__(256) void loss_slots_sum_kernel(const float* __restrict__ slots, const SlotTerms terms,
+                                                             float* __restrict__ out) {
+    __shared__ float red[4];
+    const int t = blockIdx.x;
+    float total = 0.f;
+    for (int sl = terms.first[t]; sl < terms.first[t + 1]; sl++) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(slots + (long)sl * kSlot)[threadIdx.x];
+        const float r = block_sum_256((v[0] + v[1]) + (v[2] + v[3]), red);
+        total += r;   // meaningful in thread 0 only
+    }
+    if (threadIdx.x == 0) out[t] = total;
+}
+
+int loss_slots_sum_impl(const float* slots, const int* first, int nterms, float* out, hipStream_t s) {
+    SlotTerms terms;
+    for (int i = 0; i <= STMI_LOSS_TERMS_MAX; i++) terms.first[i] = first[i <= nterms ? i : nterms];
+    hipLaunchKernelGGL(loss_slots_sum_kernel, dim3(nterms), dim3(256), 0, s, slots, terms, out);
+    STMI_LAUNCH_CHECK("loss_slots_sum_kernel");
     return STMI_OK;
 }
 
 // Gram form: g fp32 [n,c,c] against target fp32 [c,c]; writes the scaled
 // difference into the K-contiguous padded layout the Gram-backward GEMM reads
 // ([n][rows_pad][kpad], zero padding).  (dG + dG^T)/2 needs the transposed element as well: a
-// block owns a TS x TS tile, brings the mirrored tile's differences through LDS (both tiles are
-// read along their rows), and ends with one atomic on the loss.
+// block takes TS x TS tiles (tile t, t + grid, ...), brings the mirrored tile's differences through LDS
+// (both tiles are read along their rows), and ends with its partial sum in the loss slot.
 template <typename T, int TS>
 __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__ g, const float* __restrict__ target,
-                                                       T* __restrict__ sout, float* loss, float loss_scale,
+                                                       T* __restrict__ sout, float* slot, float loss_scale,
                                                        float grad_scale, int n, int c, int rows_pad, int kpad) {
     __shared__ float red[4];
     __shared__ float mir[TS][TS + 1];
     const int tiles_c = kpad / TS, tiles_r = (rows_pad + TS - 1) / TS;
-    int t = blockIdx.x;
-    const int b = t / (tiles_r * tiles_c);
-    t -= b * tiles_r * tiles_c;
-    const int row0 = (t / tiles_c) * TS, col0 = (t % tiles_c) * TS;
-    const float* gb = g + (long)b * c * c;
-    // Each thread owns TS*TS/256 elements of the tile; all their loads are issued before the first use
-    // (the tile is a few KB: the kernel is one memory round trip long, not one per element).
-    constexpr int PER = TS * TS / 256;
-    float dm[PER], dd[PER];
-    // mirrored tile: element (col0 + i, row0 + j), read along j
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int e = threadIdx.x + u * 256;
-        const int i = e / TS, j = e - i * TS;
-        const int r = col0 + i, q = row0 + j;
-        dm[u] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
-        const int row = row0 + i, col = col0 + j;
-        dd[u] = row < c && col < c ? gb[row * c + col] - target[row * c + col] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int e = threadIdx.x + u * 256;
-        const int i = e / TS, j = e - i * TS;
-        mir[i][j] = dm[u];
-    }
-    __syncthreads();
+    const int total = n * tiles_r * tiles_c;
     float acc = 0.f;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        int t = tile;
+        const int b = t / (tiles_r * tiles_c);
+        t -= b * tiles_r * tiles_c;
+        const int row0 = (t / tiles_c) * TS, col0 = (t % tiles_c) * TS;
+        const float* gb = g + (long)b * c * c;
+        // Each thread owns TS*TS/256 elements of the tile; all their loads are issued before the first use
+        // (the tile is a few KB: the kernel is one memory round trip long, not one per element).
+        constexpr int PER = TS * TS / 256;
+        float dm[PER], dd[PER];
+        // mirrored tile: element (col0 + i, row0 + j), read along j
 #pragma unroll
-    for (int u = 0; u < PER; u++) {
-        const int e = threadIdx.x + u * 256;
-        const int i = e / TS, j = e - i * TS;
-        const int row = row0 + i, col = col0 + j;
-        if (row >= rows_pad) continue;
-        float v = 0.f;
-        if (row < c && col < c) {
-            acc += dd[u] * dd[u];
-            v = grad_scale * 0.5f * (dd[u] + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
+        for (int u = 0; u < PER; u++) {
+            const int e = threadIdx.x + u * 256;
+            const int i = e / TS, j = e - i * TS;
+            const int r = col0 + i, q = row0 + j;
+            dm[u] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
+            const int row = row0 + i, col = col0 + j;
+            dd[u] = row < c && col < c ? gb[row * c + col] - target[row * c + col] : 0.f;
         }
-        sout[((long)b * rows_pad + row) * kpad + col] = from_f32<T>(v);
+        if (tile != (int)blockIdx.x) __syncthreads();   // the previous tile's mirror has been read
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = threadIdx.x + u * 256;
+            const int i = e / TS, j = e - i * TS;
+            mir[i][j] = dm[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = threadIdx.x + u * 256;
+            const int i = e / TS, j = e - i * TS;
+            const int row = row0 + i, col = col0 + j;
+            if (row >= rows_pad) continue;
+            float v = 0.f;
+            if (row < c && col < c) {
+                acc += dd[u] * dd[u];
+                v = grad_scale * 0.5f * (dd[u] + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
+            }
+            sout[((long)b * rows_pad + row) * kpad + col] = from_f32<T>(v);
+        }
     }
     const float tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss, tot * loss_scale);
+    slot_write(slot, tot * loss_scale);
 }
 
 template <typename T>
-static void launch_gram_mse(const float* g, const float* target, void* sout, float* loss, float loss_scale,
+static void launch_gram_mse(const float* g, const float* target, void* sout, float* slot, float loss_scale,
                             float grad_scale, int n, int c, int rows_pad, int kpad, hipStream_t s) {
-    // 64 x 64 tiles when the padded matrix is made of them (at most 256 blocks, i.e. same-address atomics, for
-    // the 512-channel Grams of a batch of 4); 32 x 32 for the small ones
+    // 64 x 64 tiles when the padded matrix is made of them, 32 x 32 for the small ones; at most one block per
+    // entry of the loss slot (a block then takes several tiles)
     if (rows_pad % 64 == 0 && kpad % 64 == 0) {
-        const dim3 grid(n * (rows_pad / 64) * (kpad / 64));
-        hipLaunchKernelGGL((gram_mse_kernel<T, 64>), grid, dim3(256), 0, s, g, target, (T*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+        const long tiles = (long)n * (rows_pad / 64) * (kpad / 64);
+        const dim3 grid((unsigned)(tiles < kSlot ? tiles : kSlot));
+        hipLaunchKernelGGL((gram_mse_kernel<T, 64>), grid, dim3(256), 0, s, g, target, (T*)sout, slot, loss_scale, grad_scale, n, c, rows_pad, kpad);
     } else {
-        const dim3 grid(n * ((rows_pad + 31) / 32) * (kpad / 32));
-        hipLaunchKernelGGL((gram_mse_kernel<T, 32>), grid, dim3(256), 0, s, g, target, (T*)sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad);
+        const long tiles = (long)n * ((rows_pad + 31) / 32) * (kpad / 32);
+        const dim3 grid((unsigned)(tiles < kSlot ? tiles : kSlot));
+        hipLaunchKernelGGL((gram_mse_kernel<T, 32>), grid, dim3(256), 0, s, g, target, (T*)sout, slot, loss_scale, grad_scale, n, c, rows_pad, kpad);
     }
 }
 
-int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, float loss_scale, float grad_scale,
+int gram_mse_impl(const float* g, const float* target, void* sout, float* slot, float loss_scale, float grad_scale,
                   int n, int c, int dtype, hipStream_t s) {
     const int rows_pad = packed_rows(c), kpad = round_up(c, 32);
-    if (dtype == STMI_BF16) launch_gram_mse<bf16_t>(g, target, sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
-    else launch_gram_mse<float>(g, target, sout, loss, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
+    if (dtype == STMI_BF16) launch_gram_mse<bf16_t>(g, target, sout, slot, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
+    else launch_gram_mse<float>(g, target, sout, slot, loss_scale, grad_scale, n, c, rows_pad, kpad, s);
     STMI_LAUNCH_CHECK("gram_mse_kernel");
     return STMI_OK;
 }
@@ -301,7 +346,7 @@ int gram_mse_impl(const float* g, const float* target, void* sout, float* loss, 
 // loads of all U elements (the value and its four neighbours, mostly cache hits) issued before the first use:
 // the launch is a few memory round trips long, not one per row.  32-bit indices (the launcher checks the count).
 template <typename T>
-__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, T* __restrict__ grad, float* loss,
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, T* __restrict__ grad, float* slot,
                                                  float wx, float wy, int total, int span, int h, int w, int c) {
     __shared__ float red[4];
     constexpr int U = 4;
@@ -339,10 +384,10 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ img, 
         }
     }
     const float tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss, tot);
+    slot_write(slot, tot);
 }
 
-int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int h, int w, int c, int dtype,
+int tv_impl(const float* img, void* grad, float* slot, float weight, int n, int h, int w, int c, int dtype,
             hipStream_t s) {
     // reduce_mean over [n,h,w-1,c] and [n,h-1,w,c]; a 1-wide axis gives an empty mean (NaN in TF): treated as 0 here
     const float wx = w > 1 ? weight / ((float)n * h * (w - 1) * c) : 0.f;
@@ -350,14 +395,14 @@ int tv_impl(const float* img, void* grad, float* loss, float weight, int n, int 
     const long count = (long)n * h * w * c;
     if (count == 0) return STMI_OK;
     STMI_REQUIRE(count < (1L << 31) - 256 * 8, "tv: more than 2^31 elements");
-    // at most 256 blocks (each ends with one atomic on the same address), spans a multiple of the block's stride
+    // at most 256 blocks (each ends with one entry of the loss slot), spans a multiple of the block's stride
     const int blocks = (int)(count < 256 * 1024 ? (count + 1023) / 1024 : 256);
     const int span = (int)(((count + blocks - 1) / blocks + 1023) / 1024 * 1024);
     const dim3 grid((unsigned)((count + span - 1) / span));
     if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, loss, wx, wy, (int)count, span, h, w, c);
+        hipLaunchKernelGGL(tv_kernel<bf16_t>, grid, dim3(256), 0, s, img, (bf16_t*)grad, slot, wx, wy, (int)count, span, h, w, c);
     else
-        hipLaunchKernelGGL(tv_kernel<float>, grid, dim3(256), 0, s, img, (float*)grad, loss, wx, wy, (int)count, span, h, w, c);
+        hipLaunchKernelGGL(tv_kernel<float>, grid, dim3(256), 0, s, img, (float*)grad, slot, wx, wy, (int)count, span, h, w, c);
     STMI_LAUNCH_CHECK("tv_kernel");
     return STMI_OK;
 }

@@ -312,10 +312,6 @@ def _style_table():
     return {name: StyleConfig(os.path.join(S, img), sw, cw, tv) for name, img, sw, cw, tv in rows}
 
 
-def _scalar(device):
-    return torch.zeros(1, dtype=torch.float32, device=device)
-
-
 class StyleTransfer:
     STYLE_WEIGHT = 1e-2
     TOTAL_VARIATION_WEIGHT = 1e-4
@@ -341,10 +337,10 @@ class StyleTransfer:
 
     @staticmethod
     def total_variation_loss(image):
-        loss = _scalar(image.device)
+        slot = ops.loss_slots(1, image.device)[0]
         img32 = image if image.dtype == torch.float32 else ops.cast(image, torch.float32)
-        ops.tv_loss_fwd_bwd(img32.contiguous(), loss, 1.0, torch.float32)
-        return loss[0]
+        ops.tv_loss_fwd_bwd(img32.contiguous(), slot, 1.0, torch.float32)
+        return ops.slot_total(slot)[0]
 
     @staticmethod
     def gram_matrix(input_tensor):
@@ -355,7 +351,7 @@ class StyleTransfer:
         """sum_i mean((a_i - b_i)^2); b_i may broadcast over the batch ([1,C,C] style targets)."""
         total = None
         for a, b in zip(array_1, array_2):
-            loss = _scalar(a.device)
+            loss = ops.loss_slots(1, a.device)[0]
             if a.dim() == 3 and a.dtype == torch.float32 and b.numel() == a.shape[1] * a.shape[2]:
                 n, c, _ = a.shape
                 ops.gram_mse_fwd_bwd(a.contiguous(), b.to(a.device, torch.float32).contiguous(), loss,
@@ -365,7 +361,8 @@ class StyleTransfer:
                     b = b.expand_as(a)
                 ops.mse_fwd_bwd(a.contiguous(), b.to(a.device, a.dtype).contiguous(), loss, 1.0 / a.numel(), 0.0,
                                 want_grad=False)
-            total = loss[0] if total is None else total + loss[0]
+            term = ops.slot_total(loss)[0]
+            total = term if total is None else total + term
         return total
 
     @staticmethod

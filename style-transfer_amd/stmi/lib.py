@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('STMI_LIB_PATH') or os.path.join(_HERE, '..', 'libstmi
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 PACK_FWD, PACK_DGRAD, PACK_FWD_ROWOUT, PACK_FWD_RGB, PACK_DGRAD_RGB = 0, 1, 2, 3, 4
+LOSS_SLOT_FLOATS, LOSS_TERMS_MAX = 1024, 8
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 
@@ -39,12 +40,15 @@ SIGNATURES = {
     'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_dgrad_in_sums_tiles': (_c_int, [_c_int] * 9),
     'stmi_conv2d_nhwc_dgrad_in_sums': (_c_int, [_vp] * 5 + [_c_float] + [_vp] * 4 + [_c_int, _vp] + _CONV + [_c_int, _vp]),
-    'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
+    'stmi_last_wgrad_kernel': (_c_int, [ctypes.c_char_p, _c_int]),
+    'stmi_conv2d_wgrad_ws_floats': (_c_long, _CONV + [_c_int]),
+    'stmi_conv2d_nhwc_wgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_fwd': (_c_int, [_vp] * 3 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_tile_stats_tiles': (_c_int, _CONV + [_c_int]),
     'stmi_conv2d_transpose_nhwc_fwd_tile_stats': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
     'stmi_conv2d_transpose_nhwc_dgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _vp]),
-    'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 3 + _CONV + [_c_int, _c_int, _vp]),
+    'stmi_conv2d_transpose_wgrad_ws_floats': (_c_long, _CONV + [_c_int]),
+    'stmi_conv2d_transpose_nhwc_wgrad': (_c_int, [_vp] * 4 + _CONV + [_c_int, _c_int, _vp]),
     'stmi_instance_norm_ws_floats': (_c_long, [_c_int] * 4),
     'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_stats_static': (_c_int, [_vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
@@ -53,17 +57,21 @@ SIGNATURES = {
     'stmi_instance_norm_nhwc_apply_tiles': (_c_int, [_vp, _vp, _c_int, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd_rows': (_c_int, [_vp] * 9 + [_c_int] * 7 + [_vp]),
+    'stmi_instance_norm_bwd_rows_count': (_c_int, [_c_int] * 5),
+    'stmi_instance_norm_param_grads': (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),
     'stmi_maxpool2x2_same_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_maxpool2x2_same_bwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp]),
-    'stmi_gram_nhwc_fwd': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
-    'stmi_gram_nhwc_fwd_add': (_c_int, [_vp, _vp] + [_c_int] * 5 + [_vp]),
+    'stmi_gram_ws_floats': (_c_long, [_c_int] * 5),
+    'stmi_gram_nhwc_fwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp]),
+    'stmi_gram_nhwc_fwd_add': (_c_int, [_vp, _vp, _vp] + [_c_int] * 5 + [_vp]),
     'stmi_zero_multi': (_c_int, [_vp, _vp, _c_int, _vp, _vp]),
     'stmi_gram_packed_elems': (_c_long, [_c_int, _c_int]),
     'stmi_gram_nhwc_bwd': (_c_int, [_vp, _vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_gram_mse_fwd_bwd': (_c_int, [_vp] * 4 + [_c_float, _c_float, _c_int, _c_int, _c_int, _vp]),
     'stmi_mse_fwd_bwd': (_c_int, [_vp] * 4 + [_c_float, _c_float, _c_long, _c_int, _vp]),
     'stmi_tv_loss_fwd_bwd': (_c_int, [_vp] * 3 + [_c_float] + [_c_int] * 5 + [_vp]),
+    'stmi_loss_slots_sum': (_c_int, [_vp, _vp, _c_int, _vp, _vp]),
     'stmi_adam_tf1': (_c_int, [_vp] * 4 + [_c_long] + [_c_float] * 5 + [_vp, _c_int, _vp]),
     'stmi_cast': (_c_int, [_vp, _vp, _c_long, _c_int, _c_int, _vp]),
     'stmi_pixels_to_rows': (_c_int, [_vp, _vp] + [_c_int] * 7 + [_vp]),

@@ -52,6 +52,14 @@ PROFILE = None
 PROFILE_HBM = None
 
 
+def last_wgrad_kernel():
+    """Name of the kernel the most recent weight-gradient / Gram call launched."""
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    _lib.call('stmi_last_wgrad_kernel', buf, 64)
+    return buf.value.decode()
+
+
 def last_conv_kernel():
     """Profiler name of the kernel the most recent conv forward / backward-data call launched."""
     import ctypes
@@ -261,15 +269,38 @@ def conv_dgrad_in_sums_tiles(in_hw, n, kshape, stride, dtype):
     return _lib.load().stmi_conv2d_dgrad_in_sums_tiles(n, in_hw[0], in_hw[1], ci, co, kh, kw, stride, _DT[dtype])
 
 
-def conv2d_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
+def _ws(ws, need, device):
+    """The workspace a call uses: the caller's (checked) or a fresh one of `need` floats; None when need == 0."""
+    if need == 0:
+        return None
+    if ws is None:
+        return torch.empty(need, dtype=torch.float32, device=device)
+    _chk(ws, 'ws', torch.float32)
+    if ws.numel() < need:
+        raise ValueError('ws holds %d floats, this call needs %d' % (ws.numel(), need))
+    return ws
+
+
+def conv2d_wgrad_ws_floats(x_shape, kshape, stride, dtype):
+    """Floats of workspace conv2d_wgrad needs for the partial sums of its pixel slices (0: none)."""
+    kh, kw, ci, co = kshape
+    n, h, w, _ = x_shape
+    return int(_lib.load().stmi_conv2d_wgrad_ws_floats(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
+def conv2d_wgrad(x, dy, kshape, stride, out=None, accumulate=False, ws=None):
+    """dW fp32 [kh,kw,ci,co]; overwritten, or added to `out` when accumulate.  Bit-reproducible (no atomics):
+    pixel slices leave partial sums in `ws`, folded in a fixed order."""
     kh, kw, ci, co = kshape
     n, h, w, c = x.shape
     assert c == ci
     _chk(x, 'x')
     _chk(dy, 'dy', x.dtype, (n, same_out(h, stride), same_out(w, stride), co))
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
-    _lib.call('stmi_conv2d_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co, kh, kw, stride,
-              int(accumulate), _dt(x), _stream())
+    assert out is not None or not accumulate
+    ws = _ws(ws, conv2d_wgrad_ws_floats(x.shape, kshape, stride, x.dtype), x.device)
+    _lib.call('stmi_conv2d_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), n, h, w, ci, co, kh, kw,
+              stride, int(accumulate), _dt(x), _stream())
     return dw
 
 
@@ -319,14 +350,22 @@ def conv2d_transpose_dgrad(dy, w_packed, kshape, stride, addend=None, out=None):
     return dx
 
 
-def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None, accumulate=False):
+def conv2d_transpose_wgrad_ws_floats(x_shape, kshape, stride, dtype):
+    kh, kw, co, ci = kshape
+    n, h, w, _ = x_shape
+    return int(_lib.load().stmi_conv2d_transpose_wgrad_ws_floats(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
+def conv2d_transpose_wgrad(x, dy, kshape, stride, out=None, accumulate=False, ws=None):
     kh, kw, co, ci = kshape
     n, h, w, c = x.shape
     assert c == ci
     _chk(x, 'x')
     _chk(dy, 'dy', x.dtype, (n, h * stride, w * stride, co))
     dw = torch.empty(kshape, dtype=torch.float32, device=x.device) if out is None else _chk(out, 'out', torch.float32, kshape)
-    _lib.call('stmi_conv2d_transpose_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), n, h, w, ci, co,
+    assert out is not None or not accumulate
+    ws = _ws(ws, conv2d_transpose_wgrad_ws_floats(x.shape, kshape, stride, x.dtype), x.device)
+    _lib.call('stmi_conv2d_transpose_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), n, h, w, ci, co,
               kh, kw, stride, int(accumulate), _dt(x), _stream())
     return dw
 
@@ -411,16 +450,37 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
     return (y, stats, y32) if want_f32 else (y, stats)
 
 
+def instance_norm_bwd_rows_count(x_shape, dtype):
+    """Partial rows per sample instance_norm_bwd leaves at the start of its workspace ([n, rows, 2, c])."""
+    n, h, w, c = x_shape
+    return int(_lib.load().stmi_instance_norm_bwd_rows_count(n, h, w, c, _DT[dtype]))
+
+
+def instance_norm_param_grads(rows, n, c, dscale, dshift, accumulate=False):
+    """dshift / dscale fp32 [c] from the partial rows of a norm's backward reduction ([n, r, 2, c], or the
+    workspace instance_norm_bwd used viewed that way), summed in a fixed order."""
+    _chk(rows, 'rows', torch.float32)
+    assert rows.numel() % (n * 2 * c) == 0, (tuple(rows.shape), n, c)
+    nrows = rows.numel() // (n * 2 * c)
+    _chk(dscale, 'dscale', torch.float32, (c,))
+    _chk(dshift, 'dshift', torch.float32, (c,))
+    _lib.call('stmi_instance_norm_param_grads', rows.data_ptr(), nrows, n, c, dscale.data_ptr(), dshift.data_ptr(),
+              int(accumulate), _stream())
+
+
 def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS, rows=None):
-    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c]).
+    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c]); both None: left to a later
+    instance_norm_param_grads on the rows this call reduced (`rows`, or the start of `ws`).
     rows: fp32 [n, r, 2, c] partial sums conv2d_dgrad(..., in_bwd=) left while writing dy; with them the
     reduction pass over x and dy is skipped."""
     n, h, w, c = x.shape
     _chk(x, 'x')
     _chk(dy, 'dy', x.dtype, x.shape)
     _chk(stats, 'stats', torch.float32, (n, c, 2))
+    assert (dscale is None) == (dshift is None)
     for t, nm in ((scale, 'scale'), (shift, 'shift'), (dscale, 'dscale'), (dshift, 'dshift')):
-        _chk(t, nm, torch.float32, (c,))
+        if t is not None:
+            _chk(t, nm, torch.float32, (c,))
     if ws is None and rows is None:
         ws = instance_norm_ws(n, h, w, c, x.device)
     dx = torch.empty_like(x) if out is None else _chk(out, 'out', x.dtype, x.shape)
@@ -431,11 +491,11 @@ def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, 
     def launch():
         if rows is not None:
             _lib.call('stmi_instance_norm_nhwc_bwd_rows', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
-                      shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), rows.data_ptr(),
+                      shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), rows.data_ptr(),
                       rows.shape[1], act, n, h, w, c, _dt(x), _stream())
             return
         _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
-                  shift.data_ptr(), dx.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), ws.data_ptr(), float(eps), act,
+                  shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), ws.data_ptr(), float(eps), act,
                   n, h, w, c, _dt(x), _stream())
     launch()
     if PROFILE_HBM is not None:  # read x and dy once, write dx once
@@ -473,14 +533,21 @@ def maxpool_bwd(x, dy, out=None):
 
 
 # ------------------------------------------------------------------- Gram
-def gram_fwd(f, out=None, accumulate=False):
-    """accumulate: ADD into `out`, which the caller cleared (zero_multi) -- one launch less."""
+def gram_ws_floats(f_shape, dtype):
+    """Floats of workspace gram_fwd needs for the partial sums of its pixel slices (0: none)."""
+    n, h, w, c = f_shape
+    return int(_lib.load().stmi_gram_ws_floats(n, h, w, c, _DT[dtype]))
+
+
+def gram_fwd(f, out=None, accumulate=False, ws=None):
+    """fp32 [n,c,c] = F^T F / (h w); accumulate: ADD into `out`.  Bit-reproducible (no atomics)."""
     n, h, w, c = f.shape
     _chk(f, 'f')
     g = torch.empty((n, c, c), dtype=torch.float32, device=f.device) if out is None else _chk(out, 'out', torch.float32, (n, c, c))
     assert out is not None or not accumulate
-    _lib.call('stmi_gram_nhwc_fwd_add' if accumulate else 'stmi_gram_nhwc_fwd', f.data_ptr(), g.data_ptr(), n, h, w, c,
-              _dt(f), _stream())
+    ws = _ws(ws, gram_ws_floats(f.shape, f.dtype), f.device)
+    _lib.call('stmi_gram_nhwc_fwd_add' if accumulate else 'stmi_gram_nhwc_fwd', f.data_ptr(), g.data_ptr(), _ptr(ws),
+              n, h, w, c, _dt(f), _stream())
     return g
 
 
@@ -520,12 +587,48 @@ def gram_bwd(f, s_packed, df, accumulate):
 
 
 # ----------------------------------------------------------------- losses
+# A loss call leaves its term as per-block partial sums in a "loss slot" (fp32 [LOSS_SLOT], overwritten
+# entirely); loss_slots_sum adds the slots of each term up in a fixed order.  No float atomics: loss values
+# are bit-reproducible.
+LOSS_SLOT = _lib.LOSS_SLOT_FLOATS
+
+
+def loss_slots(count, device):
+    return torch.zeros((count, LOSS_SLOT), dtype=torch.float32, device=device)
+
+
+def _chk_slot(slot):
+    _chk(slot, 'slot', torch.float32)
+    if slot.numel() != LOSS_SLOT or slot.data_ptr() % 16:
+        raise ValueError('a loss slot is %d contiguous, 16-byte aligned floats' % LOSS_SLOT)
+
+
+def loss_slots_sum(slots, first, out):
+    """out[t] = sum of slots[first[t] : first[t+1]] for every term t (first: host list of len(out) + 1 indices)."""
+    import ctypes
+    _chk(slots, 'slots', torch.float32)
+    _chk(out, 'out', torch.float32)
+    nterms = len(first) - 1
+    assert 1 <= nterms <= _lib.LOSS_TERMS_MAX and out.numel() >= nterms
+    assert first[-1] * LOSS_SLOT <= slots.numel()
+    arr = (ctypes.c_int * len(first))(*[int(v) for v in first])
+    _lib.call('stmi_loss_slots_sum', slots.data_ptr(), arr, nterms, out.data_ptr(), _stream())
+    return out
+
+
+def slot_total(slot):
+    """The term a single loss call left in `slot`, as a device tensor [1]."""
+    out = torch.empty(1, dtype=torch.float32, device=slot.device)
+    return loss_slots_sum(slot, [0, 1], out)
+
+
 def gram_mse_fwd_bwd(g, target, loss, loss_scale, grad_scale, dtype, out=None):
+    """`loss`: the loss slot that receives loss_scale * sum((g - target)^2) as partial sums."""
     n, c, _ = g.shape
     _chk(g, 'g', torch.float32, (n, c, c))
     _chk(target, 'target', torch.float32)
     assert target.numel() == c * c, 'style target must be one [c,c] Gram (broadcast over the batch)'
-    _chk(loss, 'loss', torch.float32)
+    _chk_slot(loss)
     ne = gram_packed_elems(n, c)
     s = torch.empty(ne, dtype=dtype, device=g.device) if out is None else _chk(out, 'out', dtype, (ne,))
     _lib.call('stmi_gram_mse_fwd_bwd', g.data_ptr(), target.data_ptr(), s.data_ptr(), loss.data_ptr(),
@@ -534,9 +637,10 @@ def gram_mse_fwd_bwd(g, target, loss, loss_scale, grad_scale, dtype, out=None):
 
 
 def mse_fwd_bwd(a, b, loss, loss_scale, grad_scale, want_grad=True, out=None):
+    """`loss`: the loss slot that receives loss_scale * sum((a - b)^2) as partial sums."""
     _chk(a, 'a')
     _chk(b, 'b', a.dtype, a.shape)
-    _chk(loss, 'loss', torch.float32)
+    _chk_slot(loss)
     grad = None
     if want_grad:
         grad = torch.empty_like(a) if out is None else _chk(out, 'out', a.dtype, a.shape)
@@ -546,9 +650,10 @@ def mse_fwd_bwd(a, b, loss, loss_scale, grad_scale, want_grad=True, out=None):
 
 
 def tv_loss_fwd_bwd(img_f32, loss, weight, dtype, out=None):
+    """`loss`: the loss slot that receives weight * TV(img) as partial sums."""
     n, h, w, c = img_f32.shape
     _chk(img_f32, 'img', torch.float32)
-    _chk(loss, 'loss', torch.float32)
+    _chk_slot(loss)
     grad = torch.empty(img_f32.shape, dtype=dtype, device=img_f32.device) if out is None else _chk(out, 'out', dtype, img_f32.shape)
     _lib.call('stmi_tv_loss_fwd_bwd', img_f32.data_ptr(), grad.data_ptr(), loss.data_ptr(), float(weight), n, h, w, c,
               _dt(grad), _stream())

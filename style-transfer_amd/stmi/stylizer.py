@@ -121,6 +121,7 @@ class StylizerNet:
                 if training:
                     b.dtmp = torch.empty((k, 1, 32, co) if b.rows == 'in' else (k, 1, c, 32), dtype=torch.float32,
                                          device=device)
+                    b.wg_call = ((batch, h, w, 32), (k, 1, 32, co)) if b.rows == 'in' else ((batch, h, w, c), (k, 1, c, 32))
                     b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
             # plain convolutions whose kernel can emit per-tile sums of its output: the instance norm behind
             # them skips its statistics pass (STMI_TILE_STATS=0: tuning aid, off)
@@ -167,6 +168,18 @@ class StylizerNet:
                                             self.grad_views[3 * i + 2])
                 b.conv_out = torch.empty(oshape, dtype=dtype, device=device)
                 b.y = torch.empty(oshape, dtype=dtype, device=device)
+                # The norm's backward leaves the partial rows of its reduction in a workspace of the block's own
+                # (not the shared one): the parameter gradients are folded from them beside the chain, while the
+                # chain already runs the next norm.
+                b.in_ws = ops.instance_norm_ws(batch, b.out_h, b.out_w, co, device)
+                b.in_rows = ops.instance_norm_bwd_rows_count(oshape, dtype)
+                # workspace floats of this block's weight-gradient call (partial sums of its pixel slices)
+                if kind == 'deconv':
+                    b.wg_need = ops.conv2d_transpose_wgrad_ws_floats((batch, h, w, c), b.kshape, s, dtype)
+                elif b.rows:
+                    b.wg_need = ops.conv2d_wgrad_ws_floats(b.wg_call[0], b.wg_call[1], 1, dtype)
+                else:
+                    b.wg_need = ops.conv2d_wgrad_ws_floats((batch, h, w, c), b.kshape, s, dtype)
             ws_floats = max(ws_floats, ops._lib.load().stmi_instance_norm_ws_floats(batch, b.out_h, b.out_w, co))
             self.blocks.append(b)
             h, w, c = b.out_h, b.out_w, co
@@ -195,10 +208,10 @@ class StylizerNet:
             # gradient still reading an older dconv on the side stream does not hold up the chain.
             self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(int(os.environ.get('STMI_GRAD_BUFS', '6')))]
             self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'w' not in _SERIAL else None
+            # the weight-gradient calls run in stream order on one stream: one workspace serves them all
+            self.wgrad_ws = torch.empty(max(4, max(b.wg_need for b in self.blocks)), dtype=torch.float32, device=device)
             self._readers = {}  # data_ptr of a gradient buffer -> (issue number, event) of its last side-stream reader
             self._reader_seq = 0
-        # the owner clears the row-patch weight-gradient buffers once per step (ops.ZeroList): they are then added to
-        self.dtmp_pre_zeroed = False
         self.repack()
 
     # ------------------------------------------------------------ parameters
@@ -277,9 +290,11 @@ class StylizerNet:
     # -------------------------------------------------------------- backward
     def backward(self, d_out, hi=None, lo=0):
         """d_out: gradient w.r.t. the stylized image, compute dtype [n,h,w,3].
-        Parameter gradients are ADDED into self.flat_grad, which the caller zeroes
-        once per step; the weight-gradient kernels run on a side stream beside the
-        data-gradient chain and are joined before the call returns.
+        Every parameter gradient is WRITTEN into its slice of self.flat_grad (nothing
+        to clear beforehand, no atomics: a step's gradients are bit-reproducible); the
+        weight-gradient kernels and the instance norms' parameter-gradient folds run
+        on a side stream beside the data-gradient chain and are joined before the
+        call returns.
 
         The pass can be cut into block ranges so that a data-parallel caller can
         start reducing the gradients of finished blocks: backward(d_out, hi=15,
@@ -339,36 +354,42 @@ class StylizerNet:
             dconv = self._view(w0, b)
             if b.role == 'b':
                 pending_skip = g  # d(block input) receives d(block output) unchanged
-            ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act,
-                                  ws=self.ws, out=dconv, rows=b.bwd_rows if have_rows else None)
+            ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, None, None, b.act,
+                                  ws=b.in_ws, out=dconv, rows=b.bwd_rows if have_rows else None)
+            norm_rows = b.bwd_rows if have_rows else b.in_ws[:self.n * b.in_rows * 2 * b.co]
             have_rows = False
             rows_g = None
+            wws = self.wgrad_ws
             if b.kind == 'deconv':
-                wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
+                wgrad = lambda: ops.conv2d_transpose_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, ws=wws)
             elif b.rows == 'in':      # rows_buf still holds the forward's input patches, unless the forward
                 def wgrad():          # ran the 3-channel kernel: then they are made here, beside the chain
                     if b.rgb and not self._rows0_ready:
                         x32 = self._x_f32
                         ops.cast(x32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x32)
                         ops.pixels_to_rows(self.x_in, b.k, -b.pad_left, out=b.rows_buf)
-                    ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
+                    ops.conv2d_wgrad(b.rows_buf, dconv, (b.k, 1, 32, b.co), 1, out=b.dtmp, ws=wws)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 0, out=b.dW)
             elif b.rows == 'out' and b.rgb_bwd:   # row patches of dconv: for the weight gradient only
                 def wgrad():
                     rg = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
-                    ops.conv2d_wgrad(x_in, rg, (b.k, 1, b.ci, 32), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
+                    ops.conv2d_wgrad(x_in, rg, (b.k, 1, b.ci, 32), 1, out=b.dtmp, ws=wws)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             elif b.rows == 'out':
                 rows_g = ops.pixels_to_rows(dconv, b.k, b.pad_left - (b.k - 1), out=b.rows_gbuf)
 
                 def wgrad():
-                    ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp, accumulate=self.dtmp_pre_zeroed)
+                    ops.conv2d_wgrad(x_in, rows_g, (b.k, 1, b.ci, 32), 1, out=b.dtmp, ws=wws)
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             else:
-                wgrad = lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, accumulate=True)
+                wgrad = lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, ws=wws)
+
+            def param_grads(wgrad=wgrad, b=b, norm_rows=norm_rows):
+                wgrad()
+                ops.instance_norm_param_grads(norm_rows, self.n, b.co, b.dscale, b.dshift)
             forked = fork()
             if i == 0:
-                on_side(w0, wgrad, forked)
+                on_side(w0, param_grads, forked)
                 break
             n_in = self.n * b.in_h * b.in_w * b.ci
             dx = w1[:n_in].view(self.n, b.in_h, b.in_w, b.ci)
@@ -387,7 +408,7 @@ class StylizerNet:
                     in_bwd = (below.conv_out, below.stats, below.scale, below.shift, below.act, below.bwd_rows)
                     have_rows = True
                 ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx, in_bwd=in_bwd)
-            on_side(w0, wgrad, forked)
+            on_side(w0, param_grads, forked)
             if b.role == 'a':
                 pending_skip = None
             g = dx

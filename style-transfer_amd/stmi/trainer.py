@@ -118,6 +118,7 @@ class StyleTrainer:
         self.rep_loss = self.vgg.replica(batch, height, width, keep_for_backward=True)
         self.batch_in = torch.empty((batch, height, width, 3), dtype=torch.float32, device=device)
         self.losses = torch.zeros(4, dtype=torch.float32, device=device)  # total, style, content, tv
+        self.loss_slots = ops.loss_slots(self.rep_loss.LOSS_SLOTS, device)   # per-block partial sums of the terms
         self.m = torch.zeros_like(self.net.flat)
         self.v = torch.zeros_like(self.net.flat)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
@@ -127,12 +128,10 @@ class StyleTrainer:
             self.buckets = GradBuckets(self.net.flat_grad, [self.net.param_range(hi, lo) for hi, lo in BWD_SEGMENTS],
                                        group)
         self._graphs = None
-        # every accumulator of a step cleared by ONE launch, which also advances the Adam step counter
-        dtmps = [b.dtmp for b in self.net.blocks if b.rows]
-        self._zero = ops.ZeroList([self.losses, self.net.flat_grad] + list(self.rep_loss.grams) + dtmps,
-                                  step_dev=self.step_dev)
-        self.rep_loss.grams_pre_zeroed = True
-        self.net.dtmp_pre_zeroed = True
+        # Nothing of a step is accumulated with atomics, so nothing has to be cleared: every gradient, Gram matrix
+        # and loss term is written by the kernel (or the fixed-order fold) that owns it.  The step begins by
+        # advancing the Adam step counter.
+        self._zero = ops.ZeroList([], step_dev=self.step_dev)
         # the content targets only meet the rest of the step at the content loss
         self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'c' not in _SERIAL else None
 
@@ -175,7 +174,9 @@ class StyleTrainer:
                 for _ in steps:
                     pass
         d_out = self.rep_loss.loss_and_grad(out, self.style_targets, self.rep_content.content,
-                                            self.sw, self.cw, self.tvw, self.losses, content_stream=cs)
+                                            self.sw, self.cw, self.tvw, self.loss_slots, content_stream=cs)
+        # every loss kernel has been issued and joined: one launch turns their partial sums into the three terms
+        ops.loss_slots_sum(self.loss_slots, self.rep_loss.LOSS_TERMS, self.losses)
         return d_out
 
     def _adam(self, lo=0, hi=None, advance=True):
@@ -319,8 +320,8 @@ class GatysOptimizer:
         self.v = torch.zeros_like(self.image)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.losses = torch.zeros(4, dtype=torch.float32, device=device)
-        self._zero = ops.ZeroList([self.losses] + list(self.rep.grams), step_dev=self.step_dev)
-        self.rep.grams_pre_zeroed = True
+        self.loss_slots = ops.loss_slots(self.rep.LOSS_SLOTS, device)
+        self._zero = ops.ZeroList([], step_dev=self.step_dev)   # nothing to clear (no atomics): advances the step counter
         self._graph = None
 
     def set_style_image(self, style_f32):
@@ -333,7 +334,8 @@ class GatysOptimizer:
     def _run(self):
         self._zero.run()
         d = self.rep.loss_and_grad(self.image, self.style_targets, self.content_target, self.sw, self.cw, self.tvw,
-                                   self.losses)
+                                   self.loss_slots)
+        ops.loss_slots_sum(self.loss_slots, self.rep.LOSS_TERMS, self.losses)
         if self.dtype == torch.float32:
             g = d
         else:

@@ -115,6 +115,10 @@ class VggReplica:
             self._scratch = [torch.empty(scratch_need, dtype=dt, device=dev) for _ in range(3)]
         self.grams = [torch.empty((batch, self.shape[nm][3], self.shape[nm][3]), dtype=torch.float32, device=dev)
                       for nm in self.style_names]
+        # partial sums of the Gram kernels' pixel slices (folded in a fixed order: no atomics); the five Gram
+        # jobs of a pass run in stream order on one stream, so they share one workspace
+        need = max(ops.gram_ws_floats(self.shape[nm], dt) for nm in self.style_names)
+        self.gram_ws = torch.empty(max(need, 4), dtype=torch.float32, device=dev)
         self.content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
         if keep:
             self.s_packed = [torch.empty(ops.gram_packed_elems(batch, self.shape[nm][3]), dtype=dt, device=dev)
@@ -134,7 +138,6 @@ class VggReplica:
         self._style_job = None
         self._deferred = []  # (event at the fork point, job) not yet issued on the side stream
         self._style_done = {}  # style layer index (or 'tv') -> event on the side stream after its loss term and gradient
-        self.grams_pre_zeroed = False  # the owner clears self.grams once per step (ops.ZeroList): gram_fwd then only adds
 
     def _buf(self, pool, shape, avoid):
         n = shape[0] * shape[1] * shape[2] * shape[3]
@@ -230,7 +233,7 @@ class VggReplica:
         self._deferred.clear()
 
     def _gram_job(self, li, tensor):
-        ops.gram_fwd(tensor, out=self.grams[li], accumulate=self.grams_pre_zeroed)
+        ops.gram_fwd(tensor, out=self.grams[li], ws=self.gram_ws)
         if self._style_job is not None:
             self._style_job(li, tensor)
             if self._side is not None:
@@ -255,16 +258,21 @@ class VggReplica:
             self.content.copy_(tensor)
 
     # -------------------------------------------------------- loss + backward
-    def loss_and_grad(self, x_f32, style_targets, content_target, style_weight, content_weight, tv_weight, losses,
+    LOSS_SLOTS = 7                      # five style terms, content, tv
+    LOSS_TERMS = [0, 0, 5, 6, 7]        # loss_slots_sum: out[0] = nothing, out[1] = style, out[2] = content, out[3] = tv
+
+    def loss_and_grad(self, x_f32, style_targets, content_target, style_weight, content_weight, tv_weight, slots,
                       content_stream=None):
-        """Runs forward on x_f32, ADDS [total, style, content, tv] into `losses` (fp32 [4], device,
-        zeroed by the caller) and returns d(total)/d(x) in the compute dtype.
+        """Runs forward on x_f32, leaves the loss terms in `slots` (ops.loss_slots(LOSS_SLOTS): the caller
+        turns them into [_, style, content, tv] with ops.loss_slots_sum(slots, LOSS_TERMS, out4)) and returns
+        d(total)/d(x) in the compute dtype.
 
         style_targets: 5 fp32 [c,c] (or [1,c,c]) Grams, content_target: tensor shaped like the content tap;
         content_stream: stream that is still producing content_target (joined before its first use)."""
         assert self.keep
         net, n = self.net, self.n
-        l_style, l_content, l_tv = losses[1:2], losses[2:3], losses[3:4]
+        assert tuple(slots.shape) == (self.LOSS_SLOTS, ops.LOSS_SLOT)
+        l_content, l_tv = slots[5], slots[6]
 
         # style: sum_l mean((G_l - T_l)^2) * w / len(content outputs)   (model_utilities.py:396)
         def style_term(li, tap):
@@ -272,7 +280,7 @@ class VggReplica:
             c = self.shape[nm][3]
             hw = self.shape[nm][1] * self.shape[nm][2]
             ls = style_weight / float(n * c * c)
-            ops.gram_mse_fwd_bwd(self.grams[li], style_targets[li], l_style, ls, 4.0 * ls / hw, net.dtype,
+            ops.gram_mse_fwd_bwd(self.grams[li], style_targets[li], slots[li], ls, 4.0 * ls / hw, net.dtype,
                                  out=self.s_packed[li])
             # d(style term)/d(tap) = tap x S: everything it needs exists already, so it leaves the
             # backward chain and joins it later as the addend of a data-gradient kernel

@@ -51,7 +51,7 @@ def test_argument_errors_are_reported_not_crashed():
     assert b'dtype' in h.stmi_last_error()
     assert h.stmi_adam_tf1(1, 1, 1, 1, 10, 1e-3, .9, .999, 1e-8, 1.0, None, 0, None) == -1
     with pytest.raises(lib.StmiError, match='bad arguments'):
-        lib.call('stmi_gram_nhwc_fwd', None, None, 1, 4, 4, 8, lib.F32, None)
+        lib.call('stmi_gram_nhwc_fwd', None, None, None, 1, 4, 4, 8, lib.F32, None)
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -276,12 +276,10 @@ def test_gatys_steps_bf16(cuda):
         print('Gatys 30 steps %s: total loss %.1f (fp32 %.1f), PSNR vs fp32 picture %.2f dB'
               % (key, final[key][0], f32[0], psnr(final[key][1], f32[1])))
         assert abs(final[key][0] - f32[0]) <= 0.1 * f32[0], (final[key][0], f32[0])
-    # graph replay against eager launches: the same kernels in the same order; the Gram matrices are summed
-    # by float atomics whose order is free, so the pictures agree closely, not bit for bit
-    assert psnr(final[(torch.bfloat16, False)][1], final[(torch.bfloat16, True)][1]) >= 45.0
-    # (measured over repeated runs: the 30-step bf16 loss ends at one of two values 1.1e-3 apart, in either mode,
-    # and the fp32 one moves by 2 % from run to run: one flipped bf16 rounding early on is amplified by Adam)
-    assert abs(final[(torch.bfloat16, False)][0] - final[(torch.bfloat16, True)][0]) <= 5e-3 * f32[0]
+    # graph replay against eager launches: the same kernels in the same order, and no kernel accumulates with
+    # float atomics -- 30 steps end on the same picture and the same loss, bit for bit
+    assert torch.equal(final[(torch.bfloat16, False)][1], final[(torch.bfloat16, True)][1])
+    assert final[(torch.bfloat16, False)][0] == final[(torch.bfloat16, True)][0]
 
 
 def test_style_swap_after_graph_capture(cuda):

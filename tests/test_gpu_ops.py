@@ -597,13 +597,87 @@ def test_gram_fwd_bwd(cuda, dtype, shape):
     fd = f.to(cuda, dtype)
     g = ops.gram_fwd(fd)
     assert rel_err(g, g_ref) <= (1e-3 if dtype == torch.float32 else 1e-2)
-    loss = torch.zeros(1, device=cuda)
+    slot = ops.loss_slots(1, cuda)[0]
     ls = mult / (n * c * c)
-    s = ops.gram_mse_fwd_bwd(g, target.to(cuda, torch.float32), loss, ls, 4.0 * ls / (h * w), dtype)
+    s = ops.gram_mse_fwd_bwd(g, target.to(cuda, torch.float32), slot, ls, 4.0 * ls / (h * w), dtype)
+    loss = ops.slot_total(slot)
     assert abs(loss.item() - loss_ref.item()) <= (1e-3 if dtype == torch.float32 else 3e-2) * abs(loss_ref.item())
     df = torch.ones(shape, device=cuda, dtype=dtype)
     ops.gram_bwd(fd, s, df, accumulate=True)
     assert rel_err(df, gf + 1.0) <= TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('chans', [(128, 128), (64, 32), (24, 40)], ids=['lds_dma_128', 'lds_dma_64x32', 'register_staged'])
+def test_wgrad_and_gram_pixel_slices_fold_in_fixed_order(cuda, dtype, chans):
+    """Geometries whose output tiles are cut into several pixel slices (a workspace is needed): the result is
+    the same bits on every run, `accumulate` adds to what the output holds, and a caller workspace works."""
+    from stmi import ops
+    ci, co = chans
+    n, h, w, k = 4, 40, 36, 3
+    x, dy = rnd((n, h, w, ci), 1), rnd((n, h, w, co), 2)
+    xq = q(x, dtype)
+    wz = torch.zeros((k, k, ci, co), dtype=torch.float64, requires_grad=True)
+    (gw_ref,) = torch.autograd.grad(O.conv2d_same(xq, wz, 1), wz, q(dy, dtype))
+    xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
+    need = ops.conv2d_wgrad_ws_floats(xd.shape, (k, k, ci, co), 1, dtype)
+    assert need > 0, 'this geometry is meant to need pixel slices'
+    ws = torch.full((need + 8,), float('nan'), device=cuda)   # stale workspace contents must not matter
+    first = ops.conv2d_wgrad(xd, dyd, (k, k, ci, co), 1, ws=ws)
+    assert rel_err(first, gw_ref) <= TOL[dtype]
+    expect = {(128, 128): 'wgrad_glds_kernel', (64, 32): 'wgrad_glds_kernel', (24, 40): 'wgrad_kernel'}[chans]
+    assert ops.last_wgrad_kernel() == expect
+    for _ in range(3):
+        assert torch.equal(ops.conv2d_wgrad(xd, dyd, (k, k, ci, co), 1), first)
+    acc = torch.full_like(first, 2.0)
+    ops.conv2d_wgrad(xd, dyd, (k, k, ci, co), 1, out=acc, accumulate=True, ws=ws)
+    assert rel_err(acc - 2.0, gw_ref) <= TOL[dtype]
+    with pytest.raises(ValueError):
+        ops.conv2d_wgrad(xd, dyd, (k, k, ci, co), 1, ws=ws[:need - 1])
+    # Gram matrix of the same tensor: one sample's 1440 pixels in several slices
+    g_ref = O.gram_matrix(xq)
+    gneed = ops.gram_ws_floats(xd.shape, dtype)
+    g1 = ops.gram_fwd(xd)
+    assert rel_err(g1, g_ref) <= (1e-3 if dtype == torch.float32 else 1e-2)
+    for _ in range(3):
+        assert torch.equal(ops.gram_fwd(xd, ws=torch.empty(max(gneed, 4), device=cuda)), g1)
+    g2 = torch.full_like(g1, -1.0)
+    ops.gram_fwd(xd, out=g2, accumulate=True)
+    assert rel_err(g2 + 1.0, g_ref) <= (1e-3 if dtype == torch.float32 else 1e-2)
+
+
+def test_wgrad_without_workspace_is_refused(cuda):
+    """Through the C-ABI: a geometry that needs pixel slices, called with ws = NULL, is an error, not a fault."""
+    from stmi import lib, ops
+    x = torch.zeros((4, 40, 36, 128), device=cuda)
+    dy = torch.zeros((4, 40, 36, 128), device=cuda)
+    dw = torch.zeros((3, 3, 128, 128), device=cuda)
+    assert ops.conv2d_wgrad_ws_floats(x.shape, (3, 3, 128, 128), 1, torch.float32) > 0
+    with pytest.raises(lib.StmiError, match='workspace'):
+        lib.call('stmi_conv2d_nhwc_wgrad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, 4, 40, 36, 128, 128, 3, 3, 1,
+                 0, lib.F32, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_instance_norm_param_grads_fixed_order(cuda, dtype):
+    """dscale / dshift from the backward's partial rows as a launch of its own: equal to what the backward call
+    adds itself, identical on every run, and batch-order independent in value only up to rounding."""
+    from stmi import ops
+    n, h, w, c = 4, 24, 20, 64
+    x, dy = rnd((n, h, w, c), 1), rnd((n, h, w, c), 2)
+    scale, shift = rnd((c,), 3).to(cuda, torch.float32), rnd((c,), 4).to(cuda, torch.float32)
+    xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
+    _, stats = ops.instance_norm_fwd(xd, scale, shift, ops.ACT_RELU)
+    ds_a, dh_a = torch.zeros(c, device=cuda), torch.zeros(c, device=cuda)
+    dx_a = ops.instance_norm_bwd(xd, dyd, stats, scale, shift, ds_a, dh_a, ops.ACT_RELU)
+    ws = ops.instance_norm_ws(n, h, w, c, cuda)
+    dx_b = ops.instance_norm_bwd(xd, dyd, stats, scale, shift, None, None, ops.ACT_RELU, ws=ws)
+    rows = ws[:n * ops.instance_norm_bwd_rows_count(xd.shape, dtype) * 2 * c]
+    ds_b, dh_b = torch.full((c,), 9.0, device=cuda), torch.full((c,), 9.0, device=cuda)
+    ops.instance_norm_param_grads(rows, n, c, ds_b, dh_b)
+    assert torch.equal(dx_a, dx_b) and torch.equal(ds_a, ds_b) and torch.equal(dh_a, dh_b)
+    ops.instance_norm_param_grads(rows, n, c, ds_b, dh_b, accumulate=True)
+    assert rel_err(ds_b, 2.0 * ds_a) <= 1e-6 and rel_err(dh_b, 2.0 * dh_a) <= 1e-6
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
@@ -613,24 +687,32 @@ def test_losses(cuda, dtype):
     aq = q(a, dtype).requires_grad_()
     ref = ((aq - q(b, dtype)) ** 2).mean() * 3.0
     (ga,) = torch.autograd.grad(ref, aq)
-    loss = torch.zeros(1, device=cuda)
+    slot = ops.loss_slots(1, cuda)[0]
+    slot.fill_(7.0)   # a loss call overwrites its whole slot: stale contents must not leak into the term
     cnt = a.numel()
-    g = ops.mse_fwd_bwd(a.to(cuda, dtype), b.to(cuda, dtype), loss, 3.0 / cnt, 6.0 / cnt)
-    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    g = ops.mse_fwd_bwd(a.to(cuda, dtype), b.to(cuda, dtype), slot, 3.0 / cnt, 6.0 / cnt)
+    assert abs(ops.slot_total(slot).item() - ref.item()) <= 1e-4 * abs(ref.item())
     assert rel_err(g, ga) <= TOL[dtype]
 
     img = torch.rand((2, 9, 7, 3), dtype=torch.float64, generator=torch.Generator().manual_seed(3))
     iq = img.float().double().requires_grad_()
     tv_ref = O.total_variation_loss(iq) * 5.0
     (gi,) = torch.autograd.grad(tv_ref, iq)
-    loss.zero_()
-    gt = ops.tv_loss_fwd_bwd(img.to(cuda, torch.float32), loss, 5.0, dtype)
-    assert abs(loss.item() - tv_ref.item()) <= 1e-4 * abs(tv_ref.item())
+    gt = ops.tv_loss_fwd_bwd(img.to(cuda, torch.float32), slot, 5.0, dtype)
+    assert abs(ops.slot_total(slot).item() - tv_ref.item()) <= 1e-4 * abs(tv_ref.item())
     assert rel_err(gt, gi) <= TOL[dtype]
     # known answer: a constant image has zero total variation
-    loss.zero_()
-    ops.tv_loss_fwd_bwd(torch.full((1, 5, 5, 3), 0.25, device=cuda), loss, 1.0, dtype)
-    assert loss.item() == 0.0
+    ops.tv_loss_fwd_bwd(torch.full((1, 5, 5, 3), 0.25, device=cuda), slot, 1.0, dtype)
+    assert ops.slot_total(slot).item() == 0.0
+    # several terms in one launch: out[t] = sum of the slots first[t] .. first[t+1]-1
+    slots = ops.loss_slots(4, cuda)
+    vals = torch.rand((4, ops.LOSS_SLOT), generator=torch.Generator().manual_seed(5))
+    slots.copy_(vals)
+    out = torch.zeros(3, device=cuda)
+    ops.loss_slots_sum(slots, [0, 1, 1, 4], out)
+    want = [vals[0].double().sum().item(), 0.0, vals[1:4].double().sum().item()]
+    for got, w_ in zip(out.tolist(), want):
+        assert abs(got - w_) <= 1e-5 * max(1.0, abs(w_))
 
 
 def test_adam_tf1_and_small_ops(cuda):

@@ -132,19 +132,35 @@ def test_training_step_fp32(cuda, use_graph):
     v = [torch.zeros_like(p) for p in P]
     for t in range(2):
         O.adam_tf1_step(P, own_grads[t], m, v, t + 1)
-    # ... so the direction is taken over the elements whose oracle gradient is well above the gradient
-    # tolerance in both steps (elsewhere its sign is not determined at 2e-3 of the tensor's maximum, and the
-    # float atomics of the weight-gradient kernels decide it differently from run to run).
     for i, (p, mine, r, p0) in enumerate(zip(tr.net.views, P, ref_params, params)):
         assert rel_err(p, mine) <= 1e-5, 'Adam on own gradients, variable %d' % i
         p0 = torch.tensor(p0, dtype=torch.float64)
-        keep = torch.ones_like(p0, dtype=torch.bool)
-        for t in range(2):
-            g = ref[t][2][i]
-            keep &= g.abs() >= 2e-2 * g.abs().max()
-        assert keep.float().mean().item() >= 0.5, 'variable %d: too few well-determined elements' % i
-        du, dr = (p.double().cpu() - p0)[keep], (r - p0)[keep]
+        du, dr = (p.double().cpu() - p0).reshape(-1), (r - p0).reshape(-1)
         assert (du @ dr / (du.norm() * dr.norm())).item() >= 0.999, 'update direction of variable %d' % i
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_training_is_bit_reproducible(cuda, dtype):
+    """No kernel of a step accumulates with float atomics (weight gradients, Gram matrices, parameter gradients
+    of the norms and loss terms are partial sums folded in a fixed order), so repeated runs from the same state
+    -- eager launches or graph replay -- give the same bits: weights, Adam moments and losses after two steps."""
+    from stmi.trainer import StyleTrainer
+    batch, style, params, vggw, mean = small_setup()
+    runs = []
+    for use_graph in (False, True, True):
+        tr = StyleTrainer(batch.shape[0], batch.shape[1], batch.shape[2], cuda, vggw, mean, 1e-2, 1e4, 1e8,
+                          dtype=dtype, params=params, use_graph=use_graph)
+        tr.set_style_image(torch.tensor(style))
+        xb = torch.tensor(batch, device=cuda)
+        tr.step(xb)
+        first = tr.losses.clone()
+        tr.step(xb)
+        torch.cuda.synchronize()
+        runs.append((tr.net.flat.clone(), tr.m.clone(), tr.v.clone(), first, tr.losses.clone(), tr.net.flat_grad.clone()))
+        del tr
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
 
 
 def test_training_step_bf16_tracks_oracle(cuda):
