@@ -194,7 +194,9 @@ def roofline_of(eager_pass, dtype_name, workload):
 
 
 def cpu_baseline_train(batch_np, style_np, params, vggw, weights, budget_s=25.0):
-    """The oracle (torch-CPU fp32 restatement of the reference step) timed on the host cores."""
+    """The oracle (torch-CPU fp32 restatement of the reference step) timed on the host cores, on the bench's own
+    inputs, weights and FULL style picture.  Also returns what its first step computed (the four losses, the
+    stylized batch, the five Gram targets): the same-run parity gate compares the GPU's first step with it."""
     from oracle import tf_ops as O
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))))
     f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
@@ -203,22 +205,60 @@ def cpu_baseline_train(batch_np, style_np, params, vggw, weights, budget_s=25.0)
     mean = torch.zeros(3)
     m = [torch.zeros_like(p) for p in P]
     v = [torch.zeros_like(p) for p in P]
-    with torch.no_grad():
-        targets, _ = O.vgg_taps(O.vgg_preprocess(f32(style_np[:, :256, :256]), mean), W)
+    with torch.no_grad():   # once per training run (full_graph_stylizer_network.py:185): outside the timed sample
+        targets, _ = O.vgg_taps(O.vgg_preprocess(f32(style_np), mean), W)
     x = f32(batch_np)
+    first = None
     done, t0 = 0, time.perf_counter()
     while True:
-        loss, *_ = O.train_step_loss(x, P, W, targets, mean, *weights)
+        loss, s_, c_, tv_, out = O.train_step_loss(x, P, W, targets, mean, *weights)
         grads = torch.autograd.grad(loss, P)
+        if first is None:
+            first = {'losses': [loss.item(), s_.item(), c_.item(), tv_.item()], 'stylized': out.detach().clone(),
+                     'targets': [t.clone() for t in targets]}
         with torch.no_grad():
             O.adam_tf1_step(P, grads, m, v, done + 1)
         done += 1
         el = time.perf_counter() - t0
         if el > budget_s or done >= 8:
             break
-    return {'value': round(batch_np.shape[0] * done / el, 4), 'unit': 'train img/s', 'cores': torch.get_num_threads(),
+    line = {'value': round(batch_np.shape[0] * done / el, 4), 'unit': 'train img/s', 'cores': torch.get_num_threads(),
             'kind': 'port', 'sample': '%d full training steps of the same 4x256x256 workload (torch-CPU fp32 '
             'restatement of the reference step; TensorFlow itself is not installable here)' % done}
+    return line, first
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def parity_gate(cpu_first, gpu_first):
+    """Same-run parity gate: the FIRST step of the timed GPU runs against the oracle's first step on the same
+    inputs and weights (computed for the CPU baseline).  fp32 mode: the four losses, the stylized batch and the
+    Gram targets within 1e-3 (max |err| / max |ref|); bf16 mode: PSNR >= 40 dB on the stylized batch, Gram
+    targets (1.3 M pixels summed per entry) within 1e-2.  The oracle here is its fp32 evaluation (the timed CPU
+    baseline), accurate to ~1e-6 on these quantities."""
+    gate = {'oracle': 'torch-CPU fp32 restatement, first step, same inputs / weights / style picture (parity unpinned: '
+                      'no TensorFlow here)'}
+    ok = True
+    f32 = gpu_first.get('f32')
+    if f32 is not None:
+        gate['fp32_loss_rel_err'] = max(abs(g - c) / abs(c) for g, c in zip(f32['losses'], cpu_first['losses']))
+        gate['fp32_stylized_rel_err'] = _rel(f32['stylized'], cpu_first['stylized'])
+        gate['fp32_gram_target_rel_err'] = max(_rel(g.reshape(t.shape), t) for g, t in zip(f32['targets'], cpu_first['targets']))
+        ok = ok and max(gate['fp32_loss_rel_err'], gate['fp32_stylized_rel_err'], gate['fp32_gram_target_rel_err']) <= 1e-3
+    b16 = gpu_first.get('bf16')
+    if b16 is not None:
+        mse = ((b16['stylized'].double().cpu() - cpu_first['stylized'].double()) ** 2).mean().item()
+        gate['bf16_psnr_db'] = 10.0 * np.log10(1.0 / max(mse, 1e-30))
+        gate['bf16_gram_rel_err'] = max(_rel(g.reshape(t.shape), t) for g, t in zip(b16['targets'], cpu_first['targets']))
+        gate['bf16_loss_rel_err'] = max(abs(g - c) / abs(c) for g, c in zip(b16['losses'], cpu_first['losses']))
+        ok = ok and gate['bf16_psnr_db'] >= 40.0 and gate['bf16_gram_rel_err'] <= 1e-2
+    gate = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in gate.items()}
+    gate['limits'] = {'fp32': 1e-3, 'bf16_psnr_db': 40.0, 'bf16_gram': 1e-2}
+    gate['pass'] = bool(ok and (f32 is not None or b16 is not None))
+    return gate
 
 
 def run_train(args, dtype_name, steps, warmup, world, rank, device, want_roofline, want_cpu):
@@ -236,6 +276,10 @@ def run_train(args, dtype_name, steps, warmup, world, rank, device, want_rooflin
     tr.set_style_image(torch.from_numpy(style))
     tr.batch_in.copy_(torch.from_numpy(batch))
     torch.cuda.synchronize()
+    # one untimed step from the initial weights: what the same-run parity gate compares with the oracle's first step
+    tr.step()
+    first = {'losses': [float(v) for v in tr.read_losses()], 'stylized': tr.net.out_f32.detach().cpu().clone(),
+             'targets': [t.detach().cpu().clone() for t in tr.style_targets]}
     if args.host_input:
         pinned = torch.from_numpy(batch).pin_memory()
 
@@ -271,7 +315,8 @@ def run_train(args, dtype_name, steps, warmup, world, rank, device, want_rooflin
                 tr.use_graph = g
             out['roofline'] = roofline_of(eager, dtype_name, 'train')
         if want_cpu:
-            out['cpu_baseline'] = cpu_baseline_train(batch, style, params, vggw, STARRY)
+            out['cpu_baseline'], out['_cpu_first'] = cpu_baseline_train(batch, style, params, vggw, STARRY)
+    out['_gpu_first'] = first
     return out
 
 
@@ -365,6 +410,8 @@ def main():
     if args.workload == 'train':
         line.update(run_train(args, args.dtype, args.steps, args.warmup, world, rank, device, roof,
                               not args.no_cpu_baseline))
+        cpu_first = line.pop('_cpu_first', None)
+        gpu_first = {args.dtype: line.pop('_gpu_first')}
         if world == 1 and not args.no_secondary and args.batch is None and not args.host_input:
             # the other configurations the headline metric names, each with its own roofline; a failure
             # there is reported in place and never costs the headline line
@@ -375,9 +422,14 @@ def main():
             for name, job in jobs:
                 torch.cuda.empty_cache()
                 try:
-                    line['secondary'].append(dict(job(), name=name))
+                    res = dict(job(), name=name)
+                    if name == 'train_f32':
+                        gpu_first['f32'] = res.pop('_gpu_first')
+                    line['secondary'].append(res)
                 except Exception as exc:  # noqa: BLE001
                     line['secondary'].append({'name': name, 'error': repr(exc)})
+        if cpu_first is not None and rank == 0 and args.batch is None:
+            line['parity_gate'] = parity_gate(cpu_first, gpu_first)
     elif args.workload == 'infer1080p':
         line.update(run_infer(args, args.dtype, args.steps, args.warmup, world, rank, device, roof))
     else:
