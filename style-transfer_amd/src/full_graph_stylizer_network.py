@@ -165,20 +165,38 @@ def _load_vgg_for_training():
 # --------------------------------------------------------------------------
 def train_style_network(style_type, test_content_image_path=CONTENT_IMAGE_1_2, dataset_manager=None,
                         epochs=None, log=print):
+    """The reference's training loop (full_graph_stylizer_network.py:85-232).
+
+    Data parallel when started once per GPU with the torchrun environment (WORLD_SIZE, RANK, LOCAL_RANK,
+    MASTER_ADDR, MASTER_PORT): every rank loads the same images and shuffles them with the same random stream,
+    a step consumes WORLD_SIZE * BATCH_SIZE images (BATCH_SIZE per GPU), the gradients are summed over RCCL and
+    averaged, and every rank applies the same TF1-Adam update.  The ragged last batch of an epoch
+    (:196-203) is padded with images from the start of the shuffled list, identically on every rank.
+    Rank 0 alone writes config.json, losses.jsonl (its own shard's losses), the per-epoch sample and the
+    checkpoint; every rank returns the model name."""
+    from stmi import dist as stdist
     from stmi.stylizer import StylizerNet
     from stmi.trainer import StyleTrainer
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), 0
+    if world > 1:
+        world, rank, device = stdist.init_from_env()
+    else:
+        device = _device()
+    lead = rank == 0
+    if not lead:
+        log = lambda *a, **k: None
     style_config = StyleTransfer.STYLE_CONFIG_DICT[style_type]
     style_image = load_image(style_config.style_path)
     test_content_image = load_image(test_content_image_path)
-    device, dtype = _device(), _compute_dtype()
+    dtype = _compute_dtype()
     epochs = EPOCHS if epochs is None else epochs
 
     log('Building networks...')
     vgg_weights, vgg_mean = _load_vgg_for_training()
     trainer = StyleTrainer(BATCH_SIZE, TRAIN_IMG_DIMS[1], TRAIN_IMG_DIMS[2], device, vgg_weights, vgg_mean,
                            style_config.style_weight, style_config.content_weight,
-                           style_config.total_variation_weight, dtype=dtype, lr=LEARNING_RATE)
-    # the last batch of an epoch is ragged (1001 images, batch 4): it gets its own executor
+                           style_config.total_variation_weight, dtype=dtype, lr=LEARNING_RATE, world_size=world)
+    # one rank: the last batch of an epoch is ragged (1001 images, batch 4) and gets its own executor
     tail_trainers = {}
     log('Done building networks.')
 
@@ -188,57 +206,69 @@ def train_style_network(style_type, test_content_image_path=CONTENT_IMAGE_1_2, d
     log('Done loading images.')
 
     model_name = time.strftime(model_prefix + '_%Y-%m-%d-%H-%M') + '_' + style_type
+    if world > 1:
+        # one model name and ONE shuffle stream for all ranks (the lists must stay identical epoch after epoch)
+        import torch.distributed as tdist
+        shared = [model_name, int(np.random.randint(1 << 31))]
+        tdist.broadcast_object_list(shared, src=0)
+        model_name = shared[0]
+        np.random.seed(shared[1])
     target_dir = os.path.join(constants.MODELS_DIR, model_name)
-    os.mkdir(target_dir)
-    _, style_network_configs = _layer_config_strings()
-    style_network_configs['style_config'] = repr(style_config)
-    style_network_configs['style_layers'] = StyleTransfer.VGG_STYLE_TARGET_LAYER_NAMES
-    style_network_configs['content_layers'] = StyleTransfer.VGG_CONTENT_TARGET_LAYER_NAMES
-    style_network_configs['batch_size'] = BATCH_SIZE
-    style_network_configs['data_size'] = TOTAL_IMAGES
-    style_network_configs['epochs'] = epochs
-    style_network_configs['LR'] = LEARNING_RATE
-    style_network_configs['config_name'] = style_type
-    with open(os.path.join(target_dir, 'config.json'), 'w+') as fl:
-        json.dump(style_network_configs, fl, indent=4)
-    loss_log = open(os.path.join(target_dir, 'losses.jsonl'), 'w')
+    loss_log = None
+    if lead:
+        os.mkdir(target_dir)
+        _, style_network_configs = _layer_config_strings()
+        style_network_configs['style_config'] = repr(style_config)
+        style_network_configs['style_layers'] = StyleTransfer.VGG_STYLE_TARGET_LAYER_NAMES
+        style_network_configs['content_layers'] = StyleTransfer.VGG_CONTENT_TARGET_LAYER_NAMES
+        style_network_configs['batch_size'] = BATCH_SIZE
+        style_network_configs['data_size'] = TOTAL_IMAGES
+        style_network_configs['epochs'] = epochs
+        style_network_configs['LR'] = LEARNING_RATE
+        style_network_configs['config_name'] = style_type
+        with open(os.path.join(target_dir, 'config.json'), 'w+') as fl:
+            json.dump(style_network_configs, fl, indent=4)
+        loss_log = open(os.path.join(target_dir, 'losses.jsonl'), 'w')
 
     trainer.set_style_image(torch.from_numpy(np.ascontiguousarray(style_image)))
-    sampler = StylizerNet(1, test_content_image.shape[1], test_content_image.shape[2], device, dtype)
+    sampler = StylizerNet(1, test_content_image.shape[1], test_content_image.shape[2], device, dtype) if lead else None
     train_start_time = time.time()
     for epoch in range(epochs):
         dataset_manager.shuffle_loaded_images()
         images = dataset_manager.get_images()
         log('Epoch ' + str(epoch + 1) + ' of ' + str(epochs))
-        num_training_steps = int(len(images) / BATCH_SIZE) + 1
-        for step in range(num_training_steps):
-            start = min(len(images), step * BATCH_SIZE)
-            end = min(len(images), (step + 1) * BATCH_SIZE)
-            if start == end:
-                continue
-            batch = torch.from_numpy(np.ascontiguousarray(np.array(images[start:end], dtype=np.float32)))
-            if end - start == BATCH_SIZE:
+        batches = stdist.epoch_batches(len(images), BATCH_SIZE, world, rank)
+        num_training_steps = int(len(images) / BATCH_SIZE) + 1 if world == 1 else len(batches)
+        for step, index in enumerate(batches):
+            batch = torch.from_numpy(np.ascontiguousarray(np.array([images[i] for i in index], dtype=np.float32)))
+            if len(index) == BATCH_SIZE:
                 active = trainer
             else:
-                active = _tail_trainer(tail_trainers, trainer, end - start, vgg_weights, vgg_mean, style_config, dtype)
+                active = _tail_trainer(tail_trainers, trainer, len(index), vgg_weights, vgg_mean, style_config, dtype)
             active.step(batch.to(device))
             if active is not trainer:
                 _sync_back(active, trainer)
-            if step % max(int(num_training_steps / 10), 1) == 0:
+            if lead and step % max(int(num_training_steps / 10), 1) == 0:
                 total, style_l, content_l, tv_l = active.read_losses()
                 loss_log.write(json.dumps({'step': epoch * num_training_steps + step, 'total': total, 'style': style_l,
                                            'content': content_l, 'tv': tv_l}) + '\n')
                 loss_log.flush()
-        sampler.load_params(trainer.net.export_params())
-        sampler.repack()
-        sampled_image = sampler.forward(torch.from_numpy(np.ascontiguousarray(test_content_image)).to(device))
-        save_image(sampled_image.cpu().numpy(), os.path.join(target_dir, str(epoch) + '_style_transfer_sample.jpg'))
+        if lead:
+            sampler.load_params(trainer.net.export_params())
+            sampler.repack()
+            sampled_image = sampler.forward(torch.from_numpy(np.ascontiguousarray(test_content_image)).to(device))
+            save_image(sampled_image.cpu().numpy(), os.path.join(target_dir, str(epoch) + '_style_transfer_sample.jpg'))
         elapsed = time.time() - train_start_time
         eta = (elapsed / max(1, epoch + 1)) * (epochs - (epoch + 1))
         log('elapsed: ' + str(elapsed / 60.)[:6] + ' min | remaining training time: ' + str(eta / 60.)[:6] + ' min')
     log('Training concluded. Saving model...')
-    save_checkpoint(trainer.net.export_params(), target_dir, model_name, global_step=0)
-    loss_log.close()
+    if lead:
+        save_checkpoint(trainer.net.export_params(), target_dir, model_name, global_step=0)
+        loss_log.close()
+    if world > 1:
+        import torch.distributed as tdist
+        torch.cuda.synchronize()
+        tdist.barrier()   # no rank leaves (and tears the group down) while another still reduces
     log('Model saved.')
     return model_name
 

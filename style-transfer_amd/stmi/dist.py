@@ -13,17 +13,49 @@ def shard_frames(num_frames, rank, world):
     return range(start, start + base + (1 if rank < rem else 0))
 
 
-def init_from_env(backend='nccl'):
-    """(world, rank, device) from the torchrun environment; no-op for a single process."""
+def init_from_env(backend=None):
+    """(world, rank, device) from the torchrun environment (WORLD_SIZE, RANK, LOCAL_RANK, MASTER_*); no-op for a
+    single process.  backend: 'nccl' (RCCL, one GPU per rank; the default) or 'gloo' (rehearsals with several
+    ranks on one GPU: set STMI_DIST_BACKEND=gloo and give every rank the LOCAL_RANK of the GPU to share)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     device = torch.device('cuda', local)
-    if world > 1 and not torch.distributed.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = backend or os.environ.get('STMI_DIST_BACKEND', 'nccl')
+    if world > 1:
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+        if not torch.distributed.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if backend == 'nccl':
+                torch.distributed.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+            else:
+                torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     return world, rank, device
+
+
+def epoch_batches(num_images, batch, world, rank):
+    """Index lists of one epoch's batches for `rank`: the reference's loop (full_graph_stylizer_network.py:196-203)
+    cut for `world` data-parallel ranks.
+
+    One rank: int(n / batch) + 1 batches of consecutive images, the last one ragged (possibly empty: skipped), as
+    the reference runs them.  Several ranks: a step consumes world * batch consecutive images of the (identically
+    shuffled) list, rank r the r-th group of `batch`; every rank runs the same number of steps with full batches;
+    the ragged tail is PADDED with images from the start of the list, the same way on every rank, so that every
+    image is still seen once per epoch and no rank waits for another."""
+    if world == 1:
+        out = []
+        for step in range(int(num_images / batch) + 1):
+            start, end = min(num_images, step * batch), min(num_images, (step + 1) * batch)
+            if end > start:
+                out.append(list(range(start, end)))
+        return out
+    per_step = world * batch
+    steps = -(-num_images // per_step)
+    out = []
+    for step in range(steps):
+        first = step * per_step + rank * batch
+        out.append([(first + i) % num_images for i in range(batch)])
+    return out
 
 
 class FrameStager:

@@ -81,3 +81,29 @@ def test_shard_frames_edge_cases():
     assert list(shard_frames(0, 0, 8)) == []
     assert [len(shard_frames(3, r, 8)) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
     assert [list(shard_frames(10, r, 4)) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+
+
+def test_epoch_batches_reference_loop_and_data_parallel_cut():
+    """One rank: the reference's loop (full_graph_stylizer_network.py:196-203: int(n / 4) + 1 steps, ragged tail,
+    empty tail skipped).  Several ranks: equal step counts, full batches, disjoint groups within a step, every
+    image seen, the tail padded from the start of the list identically everywhere."""
+    from stmi.dist import epoch_batches
+    for n in (1001, 1000, 5, 4, 3):
+        got = epoch_batches(n, 4, 1, 0)
+        want = []
+        for step in range(int(n / 4) + 1):           # the reference's index arithmetic
+            start, end = min(n, step * 4), min(n, (step + 1) * 4)
+            if start != end:
+                want.append(list(range(start, end)))
+        assert got == want
+    for n, world in ((1001, 8), (1001, 2), (10, 2), (64, 4), (7, 4)):
+        per_rank = [epoch_batches(n, 4, world, r) for r in range(world)]
+        steps = {len(b) for b in per_rank}
+        assert len(steps) == 1                          # no rank waits for another
+        assert all(len(ix) == 4 for b in per_rank for ix in b)
+        seen = set()
+        for s in range(steps.pop()):
+            group = [i for r in range(world) for i in per_rank[r][s]]
+            assert group == [(s * world * 4 + j) % n for j in range(world * 4)]   # consecutive, wrapped at the end
+            seen.update(group)
+        assert seen == set(range(n))
