@@ -220,10 +220,11 @@ int stmi_conv2d_transpose_nhwc_wgrad(const void* x, const void* dy, float* dw, f
  * stats  : stats[n,c,2] (fp32) = (mean, 1/sqrt(var+eps)) per sample and channel; ws is
  *          scratch of stmi_instance_norm_ws_floats floats (per-block partial sums).
  * apply  : y = act(scale*xhat + shift) [+ residual]; optional fp32 copy y_f32.
- * bwd    : from dy (gradient w.r.t. y) to dx, and ADDS the parameter gradients
- *          into dscale[c], dshift[c] (fp32; both NULL: not computed here, see
- *          stmi_instance_norm_param_grads).  The activation gradient is
- *          recomputed from x, so y is not needed.
+ * bwd    : from dy (gradient w.r.t. y) to dx, and the parameter gradients dscale[c],
+ *          dshift[c] (fp32; written, or added to what they hold when accumulate != 0;
+ *          both NULL: not computed here, see stmi_instance_norm_param_grads), summed over
+ *          samples in a fixed order by a few extra blocks of the same launch.  The
+ *          activation gradient is recomputed from x, so y is not needed.
  * Nothing in these passes uses float atomics: results are bit-reproducible, and a sample's
  * result does not depend on the batch it is part of. */
 long stmi_instance_norm_ws_floats(int n, int h, int w, int c);
@@ -262,7 +263,7 @@ int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float
                                   int dtype, void* stream);
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats,
                                 const float* scale, const float* shift,
-                                void* dx, float* dscale, float* dshift, float* ws,
+                                void* dx, float* dscale, float* dshift, int accumulate, float* ws,
                                 float eps, int act, int n, int h, int w, int c,
                                 int dtype, void* stream);
 
@@ -270,7 +271,8 @@ int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stat
  * ([n, nrows, 2, c]: sum(g), sum(g * xhat)) that stmi_conv2d_nhwc_dgrad_in_sums left behind. */
 int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float* stats,
                                      const float* scale, const float* shift,
-                                     void* dx, float* dscale, float* dshift, const float* rows, int nrows,
+                                     void* dx, float* dscale, float* dshift, int accumulate,
+                                     const float* rows, int nrows,
                                      int act, int n, int h, int w, int c, int dtype, void* stream);
 
 /* The parameter gradients of the norm from the partial rows of its backward reduction, as a launch of its

@@ -50,8 +50,8 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
 int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
-                     float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
-                     int dtype, hipStream_t s);
+                     float* dscale, float* dshift, int accumulate, const float* rows, int nrows, int act, int n, int h,
+                     int w, int c, int dtype, hipStream_t s);
 int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void* wq, const float* bias, void* y,
                       void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s,
                       float* tile_stats = nullptr);
@@ -84,7 +84,8 @@ int in_stats_static_impl(const void* x, float* stats, float eps, int n, int h, i
 int in_apply_impl(const void* x, const float* stats, const float* scale, const float* shift, const void* residual,
                   void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
-                float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c, int dtype, hipStream_t s);
+                float* dscale, float* dshift, int accumulate, float* ws, int act, int n, int h, int w, int c, int dtype,
+                hipStream_t s);
 int scale_shift_impl(const float*, const float*, void*, float, long, int, int, hipStream_t);
 int cast_impl(const void*, void*, long, int, int, hipStream_t);
 int clip_impl(float*, long, float, float, hipStream_t);
@@ -414,26 +415,28 @@ int stmi_instance_norm_nhwc_apply_tiles(const void* x, const float* tile_stats, 
 }
 
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats, const float* scale,
-                                const float* shift, void* dx, float* dscale, float* dshift, float* ws, float eps,
-                                int act, int n, int h, int w, int c, int dtype, void* stream) {
+                                const float* shift, void* dx, float* dscale, float* dshift, int accumulate, float* ws,
+                                float eps, int act, int n, int h, int w, int c, int dtype, void* stream) {
     (void)eps;  // 1/sqrt(var+eps) is taken from `stats`
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && stats && scale && shift && dx && ws && n >= 0 && h > 0 && w > 0 && c > 0 &&
                  (dscale == nullptr) == (dshift == nullptr), "instance_norm_nhwc_bwd: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd: bad activation %d", act);
     if (n == 0) return STMI_OK;
-    return in_bwd_impl(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, dtype, S(stream));
+    return in_bwd_impl(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, ws, act, n, h, w, c, dtype, S(stream));
 }
 
 int stmi_instance_norm_nhwc_bwd_rows(const void* x, const void* dy, const float* stats, const float* scale,
-                                     const float* shift, void* dx, float* dscale, float* dshift, const float* rows,
-                                     int nrows, int act, int n, int h, int w, int c, int dtype, void* stream) {
+                                     const float* shift, void* dx, float* dscale, float* dshift, int accumulate,
+                                     const float* rows, int nrows, int act, int n, int h, int w, int c, int dtype,
+                                     void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && dy && stats && scale && shift && dx && rows && nrows > 0 && n >= 0 && h > 0 && w > 0 && c > 0 &&
                  (dscale == nullptr) == (dshift == nullptr), "instance_norm_nhwc_bwd_rows: bad arguments");
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_bwd_rows: bad activation %d", act);
     if (n == 0) return STMI_OK;
-    return in_bwd_rows_impl(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, dtype, S(stream));
+    return in_bwd_rows_impl(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, rows, nrows, act, n, h, w, c, dtype,
+                            S(stream));
 }
 
 int stmi_instance_norm_bwd_rows_count(int n, int h, int w, int c, int dtype) {
@@ -514,6 +517,7 @@ int stmi_gram_mse_fwd_bwd(const float* g, const float* target, void* s_out, floa
                           float grad_scale, int n, int c, int dtype, void* stream) {
     if (check_dtype(dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(g && target && s_out && slot && n >= 0 && c > 0 && c % 8 == 0, "gram_mse_fwd_bwd: bad arguments (c=%d)", c);
+    STMI_REQUIRE(((((uintptr_t)g) | ((uintptr_t)target) | ((uintptr_t)s_out)) & 15) == 0, "gram_mse_fwd_bwd: g, target and s_out must be 16-byte aligned");
     if (n == 0) return STMI_OK;
     return gram_mse_impl(g, target, s_out, slot, loss_scale, grad_scale, n, c, dtype, S(stream));
 }

@@ -621,6 +621,9 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
             if (rc) return rc;
         }
     }
+    // the profiling name says that this call was several launches
+    const size_t used = strlen(g_last_conv_kernel);
+    snprintf(g_last_conv_kernel + used, sizeof(g_last_conv_kernel) - used, " [one launch per parity class]");
     return STMI_OK;
 }
 

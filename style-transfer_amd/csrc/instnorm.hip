@@ -476,13 +476,12 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict_
 
 // Parameter gradients of an instance norm from the partial rows of its backward reduction ([n][nrows][2C]:
 // sum(g) in [0, C), sum(g * xhat) in [C, 2C)): dshift[c] (+)= sum over samples and rows of the first,
-// dscale[c] (+)= of the second.  A block owns 64 of the 2C columns; its four waves take every fourth row
-// (loads coalesced over the columns, independent, so in flight together) and their four sums are joined in
-// wave order: one fixed summation order whatever the launch looks like around it.
-__global__ __launch_bounds__(256) void in_param_grads_kernel(const float* __restrict__ rows, int total_rows, int C,
-                                                             float* dscale, float* dshift, int accumulate) {
-    __shared__ float part[4][64];
-    const int W = 2 * C, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+// dscale[c] (+)= of the second.  A block owns 64 of the 2C columns (`cb`: which 64); its four waves take every
+// fourth row (loads coalesced over the columns, independent, so in flight together) and their four sums are
+// joined in wave order: one fixed summation order whatever the launch looks like around it.
+__device__ __forceinline__ void param_grads_block(const float* __restrict__ rows, int total_rows, int C, int cb,
+                                                  float* dscale, float* dshift, int accumulate, float (*part)[64]) {
+    const int W = 2 * C, col = cb * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float acc = 0.f;
     if (col < W) {
 #pragma unroll 8
@@ -498,18 +497,34 @@ __global__ __launch_bounds__(256) void in_param_grads_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void in_param_grads_kernel(const float* __restrict__ rows, int total_rows, int C,
+                                                             float* dscale, float* dshift, int accumulate) {
+    __shared__ float part[4][64];
+    param_grads_block(rows, total_rows, C, blockIdx.x, dscale, dshift, accumulate, part);
+}
+
 // backward pass 2 (of two): folds the partial rows of pass 1 itself, then
-// dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat))
+// dx = scale*rstd*(g - mean(g) - xhat*mean(g*xhat)).  The grid's x extent is `apply_x` apply blocks plus, when
+// the parameter gradients are wanted, ceil(2C / 64) more blocks (of sample 0 only) that fold ALL samples' rows
+// into dscale / dshift in a fixed order while the apply blocks stream the tensor: no launch of their own, no
+// atomics.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const float* __restrict__ ws, T* dx, int act, InGeom g) {
+                                                           const float* __restrict__ ws, T* dx, int act, InGeom g,
+                                                           int apply_x, float* dscale, float* dshift, int accumulate) {
     extern __shared__ float sh[];  // [2C] sums | [256] scratch
     const int CG = g.C / V, slots = 256 / CG;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
+    if ((int)blockIdx.x >= apply_x) {
+        if (n == 0)
+            param_grads_block(ws, g.N * g.S, g.C, blockIdx.x - apply_x, dscale, dshift, accumulate,
+                              reinterpret_cast<float(*)[64]>(sh));
+        return;
+    }
     fold_rows_block(ws + (long)n * g.S * 2 * g.C, g.S, g.C, sh, sh + 2 * g.C);
     if (tid >= slots * CG) return;
     const int slot = tid / CG, cg = tid - slot * CG;
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* __restrict__
         shf[j] = shift[c];
     }
     const long sample = (long)n * g.HW * g.C;
-    const int stride = gridDim.x * slots;
+    const int stride = apply_x * slots;
     for (int pix0 = blockIdx.x * slots + slot; pix0 < g.HW; pix0 += stride * kInPpt) {
         float v[kInPpt][V], d[kInPpt][V];
 #pragma unroll
@@ -699,18 +714,19 @@ int in_bwd_rows_count(int n, int h, int w, int c, int dtype) {
 
 template <typename T>
 static int bwd_typed(const void* x, const void* dy, const float* stats, const float* scale, const float* shift,
-                     void* dx, float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c,
-                     hipStream_t s) {
+                     void* dx, float* dscale, float* dshift, int accumulate, float* ws, int act, int n, int h, int w,
+                     int c, hipStream_t s) {
     const InGeom g = make_geom<T>(n, h, w, c);
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
         hipLaunchKernelGGL((in_bwd_reduce_kernel<T, V>), dim3(g.S, n), dim3(256), slots * 2 * c * sizeof(float), s,
                            (const T*)x, (const T*)dy, stats, scale, shift, ws, act, g);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
-                           s, (const T*)x, (const T*)dy, stats, scale, shift, (const float*)ws, (T*)dx, act, g);
+        const int ax = apply_blocks(g, slots), px = dscale ? (2 * c + 63) / 64 : 0;
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(ax + px, n), dim3(256), fold_shared_bytes(c),
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, (const float*)ws, (T*)dx, act, g, ax,
+                           dscale, dshift, accumulate);
     });
     STMI_LAUNCH_CHECK("in_bwd kernels");
-    if (dscale && dshift) return in_param_grads_impl(ws, g.S, n, c, dscale, dshift, 1, s);
     return STMI_OK;
 }
 
@@ -718,26 +734,27 @@ static int bwd_typed(const void* x, const void* dy, const float* stats, const fl
 // partial rows per sample, [n][nrows][2C]): only the apply pass runs
 template <typename T>
 static int bwd_rows_typed(const void* x, const void* dy, const float* stats, const float* scale, const float* shift,
-                          void* dx, float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h,
-                          int w, int c, hipStream_t s) {
+                          void* dx, float* dscale, float* dshift, int accumulate, const float* rows, int nrows, int act,
+                          int n, int h, int w, int c, hipStream_t s) {
     InGeom g = make_geom<T>(n, h, w, c);
     g.S = nrows;
     IN_DISPATCH(T, c, {
         const int slots = 256 / (c / V);
-        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(apply_blocks(g, slots), n), dim3(256), fold_shared_bytes(c),
-                           s, (const T*)x, (const T*)dy, stats, scale, shift, rows, (T*)dx, act, g);
+        const int ax = apply_blocks(g, slots), px = dscale ? (2 * c + 63) / 64 : 0;
+        hipLaunchKernelGGL((in_bwd_apply_kernel<T, V>), dim3(ax + px, n), dim3(256), fold_shared_bytes(c),
+                           s, (const T*)x, (const T*)dy, stats, scale, shift, rows, (T*)dx, act, g, ax, dscale, dshift,
+                           accumulate);
     });
     STMI_LAUNCH_CHECK("in_bwd_apply_kernel");
-    if (dscale && dshift) return in_param_grads_impl(rows, nrows, n, c, dscale, dshift, 1, s);
     return STMI_OK;
 }
 
 int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
-                     float* dscale, float* dshift, const float* rows, int nrows, int act, int n, int h, int w, int c,
-                     int dtype, hipStream_t s) {
+                     float* dscale, float* dshift, int accumulate, const float* rows, int nrows, int act, int n, int h,
+                     int w, int c, int dtype, hipStream_t s) {
     return dtype == STMI_BF16
-               ? bwd_rows_typed<bf16_t>(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, s)
-               : bwd_rows_typed<float>(x, dy, stats, scale, shift, dx, dscale, dshift, rows, nrows, act, n, h, w, c, s);
+               ? bwd_rows_typed<bf16_t>(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, rows, nrows, act, n, h, w, c, s)
+               : bwd_rows_typed<float>(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, rows, nrows, act, n, h, w, c, s);
 }
 
 int in_stats_impl(const void* x, float* ws, float* stats, float eps, int n, int h, int w, int c, int dtype,
@@ -818,11 +835,11 @@ int in_fwd_impl(const void* x, float* ws, float* stats, float eps, const float* 
 }
 
 int in_bwd_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
-                float* dscale, float* dshift, float* ws, int act, int n, int h, int w, int c, int dtype,
+                float* dscale, float* dshift, int accumulate, float* ws, int act, int n, int h, int w, int c, int dtype,
                 hipStream_t s) {
     return dtype == STMI_BF16
-               ? bwd_typed<bf16_t>(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, s)
-               : bwd_typed<float>(x, dy, stats, scale, shift, dx, dscale, dshift, ws, act, n, h, w, c, s);
+               ? bwd_typed<bf16_t>(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, ws, act, n, h, w, c, s)
+               : bwd_typed<float>(x, dy, stats, scale, shift, dx, dscale, dshift, accumulate, ws, act, n, h, w, c, s);
 }
 
 }  // namespace stmi

@@ -265,6 +265,8 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
                                                        float grad_scale, int n, int c, int rows_pad, int kpad) {
     __shared__ float red[4];
     __shared__ float mir[TS][TS + 1];
+    constexpr int QR = TS / 4;               // 16-byte pieces per tile row
+    constexpr int PER = TS * QR / 256;       // pieces per thread and tile (4 for 64 x 64 tiles, 1 for 32 x 32)
     const int tiles_c = kpad / TS, tiles_r = (rows_pad + TS - 1) / TS;
     const int total = n * tiles_r * tiles_c;
     float acc = 0.f;
@@ -274,40 +276,47 @@ __global__ __launch_bounds__(256) void gram_mse_kernel(const float* __restrict__
         t -= b * tiles_r * tiles_c;
         const int row0 = (t / tiles_c) * TS, col0 = (t % tiles_c) * TS;
         const float* gb = g + (long)b * c * c;
-        // Each thread owns TS*TS/256 elements of the tile; all their loads are issued before the first use
-        // (the tile is a few KB: the kernel is one memory round trip long, not one per element).
-        constexpr int PER = TS * TS / 256;
-        float dm[PER], dd[PER];
-        // mirrored tile: element (col0 + i, row0 + j), read along j
+        // Both the tile and its mirror image are read along their rows, 16 bytes per access (c is a multiple of
+        // 8, so a piece is inside the matrix or outside as a whole); all loads of a thread are issued before
+        // the first use: the kernel is one memory round trip long.
+        f32x4 dd[PER], dm[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = threadIdx.x + u * 256;
-            const int i = e / TS, j = e - i * TS;
-            const int r = col0 + i, q = row0 + j;
-            dm[u] = r < c && q < c ? gb[r * c + q] - target[r * c + q] : 0.f;
-            const int row = row0 + i, col = col0 + j;
-            dd[u] = row < c && col < c ? gb[row * c + col] - target[row * c + col] : 0.f;
+            const int i = e / QR, q4 = (e - i * QR) * 4;
+            const int row = row0 + i, col = col0 + q4;          // the tile's own piece
+            const int mrow = col0 + i, mcol = row0 + q4;        // the mirrored tile's piece
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            dd[u] = row < c && col < c ? *reinterpret_cast<const f32x4*>(gb + (long)row * c + col) -
+                                             *reinterpret_cast<const f32x4*>(target + (long)row * c + col)
+                                       : zero;
+            dm[u] = mrow < c && mcol < c ? *reinterpret_cast<const f32x4*>(gb + (long)mrow * c + mcol) -
+                                               *reinterpret_cast<const f32x4*>(target + (long)mrow * c + mcol)
+                                         : zero;
         }
         if (tile != (int)blockIdx.x) __syncthreads();   // the previous tile's mirror has been read
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = threadIdx.x + u * 256;
-            const int i = e / TS, j = e - i * TS;
-            mir[i][j] = dm[u];
+            const int i = e / QR, q4 = (e - i * QR) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) mir[i][q4 + k] = dm[u][k];
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int e = threadIdx.x + u * 256;
-            const int i = e / TS, j = e - i * TS;
-            const int row = row0 + i, col = col0 + j;
+            const int i = e / QR, q4 = (e - i * QR) * 4;
+            const int row = row0 + i, col = col0 + q4;
             if (row >= rows_pad) continue;
-            float v = 0.f;
-            if (row < c && col < c) {
-                acc += dd[u] * dd[u];
-                v = grad_scale * 0.5f * (dd[u] + mir[j][i]);  // (dG + dG^T)/2: exact also for a non-symmetric target
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc += dd[u][k] * dd[u][k];   // zero outside the matrix
+                // (dG + dG^T)/2: exact also for a non-symmetric target; element (row, col + k) mirrors (col + k, row)
+                v[k] = row < c && col < c ? grad_scale * 0.5f * (dd[u][k] + mir[q4 + k][i]) : 0.f;
             }
-            sout[((long)b * rows_pad + row) * kpad + col] = from_f32<T>(v);
+            store_vec<T, 4>(sout + ((long)b * rows_pad + row) * kpad + col, v);
         }
     }
     const float tot = block_sum_256(acc, red);

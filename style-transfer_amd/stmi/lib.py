@@ -55,8 +55,8 @@ SIGNATURES = {
     'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_fwd': (_c_int, [_vp, _vp, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_apply_tiles': (_c_int, [_vp, _vp, _c_int, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
-    'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 9 + [_c_float] + [_c_int] * 6 + [_vp]),
-    'stmi_instance_norm_nhwc_bwd_rows': (_c_int, [_vp] * 9 + [_c_int] * 7 + [_vp]),
+    'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 8 + [_c_int, _vp, _c_float] + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_bwd_rows': (_c_int, [_vp] * 8 + [_c_int, _vp] + [_c_int] * 7 + [_vp]),
     'stmi_instance_norm_bwd_rows_count': (_c_int, [_c_int] * 5),
     'stmi_instance_norm_param_grads': (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp]),
     'stmi_scale_shift': (_c_int, [_vp, _vp, _vp, _c_float, _c_long, _c_int, _c_int, _vp]),

@@ -468,9 +468,11 @@ def instance_norm_param_grads(rows, n, c, dscale, dshift, accumulate=False):
               int(accumulate), _stream())
 
 
-def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS, rows=None):
-    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c]); both None: left to a later
-    instance_norm_param_grads on the rows this call reduced (`rows`, or the start of `ws`).
+def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, ws=None, out=None, eps=IN_EPS, rows=None,
+                      accumulate=True):
+    """dx returned; parameter gradients are ADDED into dscale/dshift (fp32 [c]), or WRITTEN when accumulate is
+    False; both None: left to a later instance_norm_param_grads on the rows this call reduced (`rows`, or the
+    start of `ws`).
     rows: fp32 [n, r, 2, c] partial sums conv2d_dgrad(..., in_bwd=) left while writing dy; with them the
     reduction pass over x and dy is skipped."""
     n, h, w, c = x.shape
@@ -491,11 +493,11 @@ def instance_norm_bwd(x, dy, stats, scale, shift, dscale, dshift, act=ACT_NONE, 
     def launch():
         if rows is not None:
             _lib.call('stmi_instance_norm_nhwc_bwd_rows', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
-                      shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), rows.data_ptr(),
+                      shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), int(accumulate), rows.data_ptr(),
                       rows.shape[1], act, n, h, w, c, _dt(x), _stream())
             return
         _lib.call('stmi_instance_norm_nhwc_bwd', x.data_ptr(), dy.data_ptr(), stats.data_ptr(), scale.data_ptr(),
-                  shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), ws.data_ptr(), float(eps), act,
+                  shift.data_ptr(), dx.data_ptr(), _ptr(dscale), _ptr(dshift), int(accumulate), ws.data_ptr(), float(eps), act,
                   n, h, w, c, _dt(x), _stream())
     launch()
     if PROFILE_HBM is not None:  # read x and dy once, write dx once

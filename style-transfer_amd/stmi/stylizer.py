@@ -7,13 +7,11 @@ Activations are NHWC in the compute dtype; every buffer is allocated once, so a
 forward/backward pass is a fixed list of kernel launches that can be captured
 in a HIP graph.
 """
-import os
-
 import numpy as np
 import torch
 
-from . import ops
-from .vggnet import _SERIAL
+from . import ops, tuning
+from .tuning import SERIAL as _SERIAL
 
 # (kind, cout, k, stride, act, residual-role)
 #   residual-role: 'a' = first conv of a residual block, 'b' = second (adds the block input)
@@ -124,35 +122,32 @@ class StylizerNet:
                     b.wg_call = ((batch, h, w, 32), (k, 1, 32, co)) if b.rows == 'in' else ((batch, h, w, c), (k, 1, c, 32))
                     b.rows_gbuf = torch.empty((batch, h, w, 32), dtype=dtype, device=device) if b.rows == 'out' else None
             # plain convolutions whose kernel can emit per-tile sums of its output: the instance norm behind
-            # them skips its statistics pass (STMI_TILE_STATS=0: tuning aid, off)
+            # them skips its statistics pass
             b.tile_stats = None
-            if kind == 'conv' and b.rows is None and os.environ.get('STMI_TILE_STATS', '1') == '1':
+            if kind == 'conv' and b.rows is None and tuning.TILE_STATS:
                 ts = ops.conv_tile_stats_tiles((batch, h, w, c), b.kshape, s, dtype)
                 # only where the apply blocks fold the tile rows themselves (<= 32 tiles a sample): with more
                 # tiles the finalize launch and the epilogue cost what the statistics pass costs (measured at
                 # 128 and at 1020 tiles a sample: 21.2 -> 21.1 us and 1021 -> 1026 us per conv + norm pair)
                 # ... or where the persistent kernel leaves the rows for free (1080p planes)
-                if 0 < ts <= int(os.environ.get('STMI_TILE_STATS_MAX', '32')) or (
+                if 0 < ts <= tuning.TILE_STATS_MAX or (
                         ts > 0 and ops.conv_tile_stats_free((batch, h, w, c), b.kshape, s, dtype)):
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... the 3-channel first layer, whose statistics pass reads the largest plane of the network
-            # (STMI_TILE_STATS_RGB=0: tuning aid, off)
-            if b.rgb and os.environ.get('STMI_TILE_STATS', '1') == '1' and os.environ.get('STMI_TILE_STATS_RGB', '1') == '1':
+            if b.rgb and tuning.TILE_STATS:
                 ts = ops.conv_rgb_tile_stats_tiles(h, w, co, k)
                 if ts > 0:
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... transposed convolutions: the up-sampling kernel takes the sums from the rows it stores
-            # (STMI_TILE_STATS_UP=0: tuning aid, off)
-            if kind == 'deconv' and os.environ.get('STMI_TILE_STATS', '1') == '1' and os.environ.get('STMI_TILE_STATS_UP', '1') == '1':
+            if kind == 'deconv' and tuning.TILE_STATS:
                 ts = ops.conv_transpose_tile_stats_tiles((batch, h, w, c), b.kshape, s, dtype)
                 if ts > 0:
                     b.tile_stats = torch.zeros((batch, ts, 4, co), dtype=torch.float32, device=device)
             # ... and in the backward pass the data-gradient kernel of this block can leave the sums the
             # instance norm of the block BELOW needs (its output gradient is what the kernel writes), so
-            # that norm's backward skips its reduction pass (STMI_IN_SUMS=0: off)
+            # that norm's backward skips its reduction pass
             b.bwd_rows = None
-            if (training and i > 0 and kind == 'conv' and b.rows is None
-                    and os.environ.get('STMI_IN_SUMS', '1') == '1'):
+            if training and i > 0 and kind == 'conv' and b.rows is None and tuning.IN_SUMS:
                 ts = ops.conv_dgrad_in_sums_tiles((h, w), batch, b.kshape, s, dtype)
                 if ts > 0:
                     self.blocks[i - 1].bwd_rows = torch.zeros((batch, ts, 2, c), dtype=torch.float32, device=device)
@@ -168,11 +163,6 @@ class StylizerNet:
                                             self.grad_views[3 * i + 2])
                 b.conv_out = torch.empty(oshape, dtype=dtype, device=device)
                 b.y = torch.empty(oshape, dtype=dtype, device=device)
-                # The norm's backward leaves the partial rows of its reduction in a workspace of the block's own
-                # (not the shared one): the parameter gradients are folded from them beside the chain, while the
-                # chain already runs the next norm.
-                b.in_ws = ops.instance_norm_ws(batch, b.out_h, b.out_w, co, device)
-                b.in_rows = ops.instance_norm_bwd_rows_count(oshape, dtype)
                 # workspace floats of this block's weight-gradient call (partial sums of its pixel slices)
                 if kind == 'deconv':
                     b.wg_need = ops.conv2d_transpose_wgrad_ws_floats((batch, h, w, c), b.kshape, s, dtype)
@@ -206,7 +196,7 @@ class StylizerNet:
             biggest = max(batch * b.out_h * b.out_w * b.co for b in self.blocks)
             # Gradient buffers: g, the skip gradient, dconv, dx -- and two more, so that a weight
             # gradient still reading an older dconv on the side stream does not hold up the chain.
-            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(int(os.environ.get('STMI_GRAD_BUFS', '6')))]
+            self._g = [torch.empty(biggest, dtype=dtype, device=device) for _ in range(tuning.GRAD_BUFS)]
             self._side = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'w' not in _SERIAL else None
             # the weight-gradient calls run in stream order on one stream: one workspace serves them all
             self.wgrad_ws = torch.empty(max(4, max(b.wg_need for b in self.blocks)), dtype=torch.float32, device=device)
@@ -234,9 +224,8 @@ class StylizerNet:
         n = self.n * b.out_h * b.out_w * b.co
         return buf[:n].view(self.n, b.out_h, b.out_w, b.co)
 
-    def forward(self, x_f32, between=None):
-        """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32).
-        between(i): optional hook called after the launches of block i (a caller's side work)."""
+    def forward(self, x_f32):
+        """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32)."""
         self._x_f32 = x_f32
         if not self.blocks[0].rgb:
             ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
@@ -283,8 +272,6 @@ class StylizerNet:
             if b.role == 'b':
                 skip = None
             cur = y
-            if between is not None:
-                between(i)
         return self.out_f32
 
     # -------------------------------------------------------------- backward
@@ -292,9 +279,8 @@ class StylizerNet:
         """d_out: gradient w.r.t. the stylized image, compute dtype [n,h,w,3].
         Every parameter gradient is WRITTEN into its slice of self.flat_grad (nothing
         to clear beforehand, no atomics: a step's gradients are bit-reproducible); the
-        weight-gradient kernels and the instance norms' parameter-gradient folds run
-        on a side stream beside the data-gradient chain and are joined before the
-        call returns.
+        weight-gradient kernels run on a side stream beside the data-gradient chain
+        and are joined before the call returns.
 
         The pass can be cut into block ranges so that a data-parallel caller can
         start reducing the gradients of finished blocks: backward(d_out, hi=15,
@@ -354,9 +340,8 @@ class StylizerNet:
             dconv = self._view(w0, b)
             if b.role == 'b':
                 pending_skip = g  # d(block input) receives d(block output) unchanged
-            ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, None, None, b.act,
-                                  ws=b.in_ws, out=dconv, rows=b.bwd_rows if have_rows else None)
-            norm_rows = b.bwd_rows if have_rows else b.in_ws[:self.n * b.in_rows * 2 * b.co]
+            ops.instance_norm_bwd(b.conv_out, g, b.stats, b.scale, b.shift, b.dscale, b.dshift, b.act, ws=self.ws,
+                                  out=dconv, rows=b.bwd_rows if have_rows else None, accumulate=False)
             have_rows = False
             rows_g = None
             wws = self.wgrad_ws
@@ -383,13 +368,9 @@ class StylizerNet:
                     ops.rows_wgrad_to_hwio(b.dtmp, b.kshape, 1, out=b.dW)
             else:
                 wgrad = lambda: ops.conv2d_wgrad(x_in, dconv, b.kshape, b.s, out=b.dW, ws=wws)
-
-            def param_grads(wgrad=wgrad, b=b, norm_rows=norm_rows):
-                wgrad()
-                ops.instance_norm_param_grads(norm_rows, self.n, b.co, b.dscale, b.dshift)
             forked = fork()
             if i == 0:
-                on_side(w0, param_grads, forked)
+                on_side(w0, wgrad, forked)
                 break
             n_in = self.n * b.in_h * b.in_w * b.ci
             dx = w1[:n_in].view(self.n, b.in_h, b.in_w, b.ci)
@@ -408,7 +389,7 @@ class StylizerNet:
                     in_bwd = (below.conv_out, below.stats, below.scale, below.shift, below.act, below.bwd_rows)
                     have_rows = True
                 ops.conv2d_dgrad(dconv, b.wp_bwd, b.kshape, b.s, (b.in_h, b.in_w), addend=addend, out=dx, in_bwd=in_bwd)
-            on_side(w0, param_grads, forked)
+            on_side(w0, wgrad, forked)
             if b.role == 'a':
                 pending_skip = None
             g = dx

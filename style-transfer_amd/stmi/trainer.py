@@ -15,11 +15,10 @@ while the next range runs.
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, tuning
 from .stylizer import StylizerNet
-from .vggnet import VggFeatures, _SERIAL
-
-import os
+from .tuning import SERIAL as _SERIAL
+from .vggnet import VggFeatures
 
 
 def _segments(cuts):
@@ -37,9 +36,9 @@ def _segments(cuts):
 # the 0.40 MB behind blocks 2..0 is exposed, and a collective of that size costs its latency, not bandwidth.
 # Adam then runs per bucket, so the update of the large bucket overlaps the reduction of the small one.
 # This default was chosen on ONE rank (graph-boundary cost measured, all-reduce time estimated); it has not
-# been timed with real peers.  STMI_BWD_CUTS (tuning aid) lists the first block of every range but the last
-# one's: "3" (the default), "7", "11,7", "" (one bucket).
-BWD_SEGMENTS = _segments([c for c in os.environ.get('STMI_BWD_CUTS', '3').split(',') if c.strip()])
+# been timed with real peers.  tuning.BWD_CUTS lists the first block of every range but the last one's: "3" (the
+# default), "7", "11,7", "" (one bucket); scripts/sweep_bwd_cuts.sh times them.
+BWD_SEGMENTS = _segments(tuning.BWD_CUTS)
 
 
 def _store_targets(owner, grams):
@@ -149,34 +148,29 @@ class StyleTrainer:
     def _front(self):
         self._zero.run()
         cs = self._content_stream
-        order = os.environ.get('STMI_FRONT_ORDER', 'c')
         if cs is None:
             self.rep_content.forward(self.batch_in, want_grams=False)
             out = self.net.forward(self.batch_in)
-        elif order == 'c':
+        else:
+            # The content-target pass goes first, on its own stream, and the stylizer forward follows on the main
+            # one (issuing the stylizer first, or interleaving the two passes layer by layer, measured 8 % slower:
+            # the content pass then shares a hardware queue with the Gram jobs and runs behind them).
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
                 self.rep_content.forward(self.batch_in, want_grams=False)
             out = self.net.forward(self.batch_in)
-        else:
-            fork = torch.cuda.Event()
-            fork.record(torch.cuda.current_stream())
-            cs.wait_event(fork)
-            steps = self.rep_content.forward_steps(self.batch_in, want_grams=False)
-            per = int(order[1:]) if len(order) > 1 else 2
-
-            def some(i):
-                with torch.cuda.stream(cs):
-                    for _ in range(per):
-                        next(steps, None)
-            out = self.net.forward(self.batch_in, between=some if order[0] == 'i' else None)
-            with torch.cuda.stream(cs):
-                for _ in steps:
-                    pass
         d_out = self.rep_loss.loss_and_grad(out, self.style_targets, self.rep_content.content,
                                             self.sw, self.cw, self.tvw, self.loss_slots, content_stream=cs)
-        # every loss kernel has been issued and joined: one launch turns their partial sums into the three terms
-        ops.loss_slots_sum(self.loss_slots, self.rep_loss.LOSS_TERMS, self.losses)
+        # every loss kernel has been issued and joined: one launch turns their partial sums into the three terms.
+        # Only the host reads them: the launch goes to the stream of the weight-gradient jobs (joined by the
+        # backward pass that follows), off the data-gradient chain.
+        side = self.net._side
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.loss_slots_sum(self.loss_slots, self.rep_loss.LOSS_TERMS, self.losses)
+        else:
+            ops.loss_slots_sum(self.loss_slots, self.rep_loss.LOSS_TERMS, self.losses)
         return d_out
 
     def _adam(self, lo=0, hi=None, advance=True):

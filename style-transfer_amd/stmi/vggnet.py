@@ -10,13 +10,8 @@ constants in the reference graph).
 """
 import torch
 
-import os
-
 from . import ops
-
-# tuning aid: STMI_SERIAL containing g / w / c keeps the Gram terms / weight gradients / content
-# targets on the main stream instead of a side stream; r keeps the 3-channel layers on row patches
-_SERIAL = os.environ.get('STMI_SERIAL', '')
+from .tuning import SERIAL as _SERIAL
 
 LAYER_NAMES = [
     'conv1_1', 'relu1_1', 'conv1_2', 'relu1_2', 'pool1',

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Tests switch the library's kernel-selection knobs inside one process: the library caches every knob at first use
+# unless this is set before its first call.
+os.environ.setdefault('STMI_ENV_LIVE', '1')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'style-transfer_amd'), os.path.join(ROOT, 'style-transfer_amd', 'src')):
     if p not in sys.path:

@@ -47,9 +47,10 @@ def _images():
     return [rng.random((H, W, 3)).astype(np.float32) for _ in range(N_IMAGES)]
 
 
-def _configure(tmp):
+def _configure(tmp, patch=None):
     """Points the drop-in's module constants at the sandbox the parent prepared (the worker processes are
-    spawned: they import everything afresh)."""
+    spawned: they import everything afresh; the parent passes pytest's monkeypatch so that nothing leaks into
+    other tests)."""
     for p in (ROOT, os.path.join(ROOT, 'style-transfer_amd'), os.path.join(ROOT, 'style-transfer_amd', 'src')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -58,11 +59,17 @@ def _configure(tmp):
     import model_utilities as mu
     import vgg
     mat = os.path.join(tmp, 'vgg.mat')
-    vgg.VGG_PATH = vgg.VGG_PATH_REPLICATE = mat
-    vgg.vgg_preprocessing_mean = np.array([0, 0, 0])
-    constants.MODELS_DIR = os.path.join(tmp, 'models')
-    fg.TRAIN_IMG_DIMS = [None, H, W, 3]
-    mu.StyleTransfer.STYLE_CONFIG_DICT['unit_test_style'] = mu.StyleConfig(os.path.join(tmp, 'style.jpg'), *WEIGHTS)
+    put = setattr if patch is None else patch.setattr
+    put(vgg, 'VGG_PATH', mat)
+    put(vgg, 'VGG_PATH_REPLICATE', mat)
+    put(vgg, 'vgg_preprocessing_mean', np.array([0, 0, 0]))
+    put(constants, 'MODELS_DIR', os.path.join(tmp, 'models'))
+    put(fg, 'TRAIN_IMG_DIMS', [None, H, W, 3])
+    cfg = mu.StyleConfig(os.path.join(tmp, 'style.jpg'), *WEIGHTS)
+    if patch is None:
+        mu.StyleTransfer.STYLE_CONFIG_DICT['unit_test_style'] = cfg
+    else:
+        patch.setitem(mu.StyleTransfer.STYLE_CONFIG_DICT, 'unit_test_style', cfg)
     return fg
 
 
@@ -85,9 +92,9 @@ def _worker(rank, world, port, tmp, q):
             dist.destroy_process_group()
 
 
-def test_train_style_network_two_ranks(cuda, tmp_path):
+def test_train_style_network_two_ranks(cuda, tmp_path, monkeypatch):
     tmp = str(tmp_path)
-    fg = _configure(tmp)
+    fg = _configure(tmp, monkeypatch)
     import image_utilities as iu
     import vgg
     from oracle import tf_ops as O

@@ -165,18 +165,33 @@ def test_parity_classes_in_one_launch_equal_one_launch_per_class(cuda, dtype, sh
     x = rnd((n, h, w, ci), 1).to(cuda, dtype)
     wt = rnd((k, k, co, ci), 2, 1.0 / np.sqrt(k * k * ci)).to(cuda, torch.float32)
     wp = ops.pack_conv_weights(wt, ops.PACK_DGRAD, dtype)
+    # three routes for the same call: the LDS-resident-patch kernel (all classes in one pass), the gather-GEMM with
+    # the classes as sub-grids of one launch, one gather-GEMM launch per class
+    up2 = ops.conv2d_transpose_fwd(x, wp, (k, k, co, ci), s)
+    name_default = ops.last_conv_kernel()
+    monkeypatch.setenv('STMI_NO_UP2', '1')
     merged = ops.conv2d_transpose_fwd(x, wp, (k, k, co, ci), s)
+    name_merged = ops.last_conv_kernel()
     monkeypatch.setenv('STMI_NO_PC_MULTI', '1')
     per_class = ops.conv2d_transpose_fwd(x, wp, (k, k, co, ci), s)
+    name_per_class = ops.last_conv_kernel()
+    # the knobs really switched the route (the library re-reads them: STMI_ENV_LIVE is set in conftest.py)
+    assert 'conv_gemm_pc_kernel' in name_merged and 'per parity class' not in name_merged, name_merged
+    assert 'per parity class' in name_per_class, name_per_class
+    assert name_default != name_per_class
     assert torch.equal(merged, per_class)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2       # another kernel, another summation order
+    assert ((up2.double() - merged.double()).abs().max() / merged.double().abs().max()).item() <= tol
     # the same for the backward-data of a stride-2 convolution on an odd-sized input
     hin, win = 2 * h - 1, 2 * w - 1
     dy = rnd((n, h, w, co), 3).to(cuda, dtype)
     w2 = rnd((k, k, ci, co), 4, 1.0 / np.sqrt(k * k * ci)).to(cuda, torch.float32)
     wp2 = ops.pack_conv_weights(w2, ops.PACK_DGRAD, dtype)
     a = ops.conv2d_dgrad(dy, wp2, (k, k, ci, co), s, (hin, win))
+    assert 'per parity class' in ops.last_conv_kernel()
     monkeypatch.delenv('STMI_NO_PC_MULTI')
     b = ops.conv2d_dgrad(dy, wp2, (k, k, ci, co), s, (hin, win))
+    assert 'per parity class' not in ops.last_conv_kernel()
     assert torch.equal(a, b)
 
 
