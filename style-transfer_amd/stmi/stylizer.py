@@ -59,7 +59,10 @@ class _Block:
 
 
 class StylizerNet:
-    def __init__(self, batch, height, width, device, dtype=torch.float32, params=None, seed=1, training=False):
+    def __init__(self, batch, height, width, device, dtype=torch.float32, params=None, seed=1, training=False,
+                 out_f32=None):
+        """out_f32: optional caller-owned fp32 [batch,height,width,3] buffer that receives the stylized batch (a
+        trainer hands in the half of its VGG input that the stylized pictures occupy)."""
         self.n, self.h, self.w = batch, height, width
         self.device, self.dtype, self.training = device, dtype, training
         shapes = param_shapes()
@@ -186,7 +189,10 @@ class StylizerNet:
         for b in self.blocks:
             b.wp_fwd = self.packed[b.off_fwd:b.off_fwd + b.n_fwd]
             b.wp_bwd = self.packed[b.off_bwd:b.off_bwd + b.n_bwd] if b.n_bwd else None
-        self.out_f32 = torch.empty((batch, h, w, 3), dtype=torch.float32, device=device)
+        if out_f32 is None:
+            out_f32 = torch.empty((batch, h, w, 3), dtype=torch.float32, device=device)
+        assert tuple(out_f32.shape) == (batch, h, w, 3) and out_f32.dtype == torch.float32 and out_f32.is_contiguous()
+        self.out_f32 = out_f32
         self.ws = torch.empty(ws_floats, dtype=torch.float32, device=device)
         if not training:
             # inference: blocks share a small pool of buffers sized for the largest activation

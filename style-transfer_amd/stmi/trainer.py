@@ -111,11 +111,23 @@ class StyleTrainer:
         self.sw, self.cw, self.tvw = style_weight, content_weight, tv_weight
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.world, self.group, self.use_graph = world_size, group, use_graph
-        self.net = StylizerNet(batch, height, width, device, dtype, params=params, seed=seed, training=True)
         self.vgg = VggFeatures(vgg_weights, vgg_mean, device, dtype)
-        self.rep_content = self.vgg.replica(batch, height, width, keep_for_backward=False)
-        self.rep_loss = self.vgg.replica(batch, height, width, keep_for_backward=True)
-        self.batch_in = torch.empty((batch, height, width, 3), dtype=torch.float32, device=device)
+        # ONE VGG pass per step over [content pictures | stylized pictures]: the frozen weights are fetched once,
+        # half the launches, and the deep layers (16 x 16 maps at 256 x 256) get twice the blocks.  The content
+        # half only passes forward: its conv5_2 output is the content target of the stylized half.
+        self.fused_vgg = tuning.FUSED_VGG
+        if self.fused_vgg:
+            self.vgg_in = torch.empty((2 * batch, height, width, 3), dtype=torch.float32, device=device)
+            self.batch_in = self.vgg_in[:batch]
+            self.net = StylizerNet(batch, height, width, device, dtype, params=params, seed=seed, training=True,
+                                   out_f32=self.vgg_in[batch:])
+            self.rep_content = None
+            self.rep_loss = self.vgg.replica(2 * batch, height, width, keep_for_backward=True, prefix=batch)
+        else:
+            self.net = StylizerNet(batch, height, width, device, dtype, params=params, seed=seed, training=True)
+            self.rep_content = self.vgg.replica(batch, height, width, keep_for_backward=False)
+            self.rep_loss = self.vgg.replica(batch, height, width, keep_for_backward=True)
+            self.batch_in = torch.empty((batch, height, width, 3), dtype=torch.float32, device=device)
         self.losses = torch.zeros(4, dtype=torch.float32, device=device)  # total, style, content, tv
         self.loss_slots = ops.loss_slots(self.rep_loss.LOSS_SLOTS, device)   # per-block partial sums of the terms
         self.m = torch.zeros_like(self.net.flat)
@@ -132,7 +144,8 @@ class StyleTrainer:
         # advancing the Adam step counter.
         self._zero = ops.ZeroList([], step_dev=self.step_dev)
         # the content targets only meet the rest of the step at the content loss
-        self._content_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' and 'c' not in _SERIAL else None
+        self._content_stream = (torch.cuda.Stream(device=device)
+                                if device.type == 'cuda' and 'c' not in _SERIAL and not self.fused_vgg else None)
 
     # ------------------------------------------------------------- targets
     def set_style_image(self, style_f32):
@@ -148,6 +161,11 @@ class StyleTrainer:
     def _front(self):
         self._zero.run()
         cs = self._content_stream
+        if self.fused_vgg:
+            self.net.forward(self.batch_in)          # the stylized pictures land behind the content pictures
+            d_out = self.rep_loss.loss_and_grad(self.vgg_in, self.style_targets, None, self.sw, self.cw, self.tvw,
+                                                self.loss_slots)
+            return self._sum_losses(d_out)
         if cs is None:
             self.rep_content.forward(self.batch_in, want_grams=False)
             out = self.net.forward(self.batch_in)
@@ -161,6 +179,9 @@ class StyleTrainer:
             out = self.net.forward(self.batch_in)
         d_out = self.rep_loss.loss_and_grad(out, self.style_targets, self.rep_content.content,
                                             self.sw, self.cw, self.tvw, self.loss_slots, content_stream=cs)
+        return self._sum_losses(d_out)
+
+    def _sum_losses(self, d_out):
         # every loss kernel has been issued and joined: one launch turns their partial sums into the three terms.
         # Only the host reads them: the launch goes to the stream of the weight-gradient jobs (joined by the
         # backward pass that follows), off the data-gradient chain.

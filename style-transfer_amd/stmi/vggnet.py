@@ -67,15 +67,20 @@ class VggFeatures:
                 L.wp_bwd_rows = ops.pack_conv_weights(wt, ops.PACK_FWD_ROWOUT, dtype)
             self.convs[name] = L
 
-    def replica(self, batch, height, width, keep_for_backward=False, relu_taps=False):
-        return VggReplica(self, batch, height, width, keep_for_backward, relu_taps)
+    def replica(self, batch, height, width, keep_for_backward=False, relu_taps=False, prefix=0):
+        """prefix: leading samples of the batch that only pass forward (a training step's content pictures, whose
+        conv5_2 output is the content target of the samples behind them); Gram matrices, loss terms and the
+        backward pass cover samples prefix .. batch-1."""
+        return VggReplica(self, batch, height, width, keep_for_backward, relu_taps, prefix)
 
 
 class VggReplica:
     """Static buffers for one input shape."""
 
-    def __init__(self, net, batch, height, width, keep, relu_taps=False):
+    def __init__(self, net, batch, height, width, keep, relu_taps=False, prefix=0):
         self.net, self.n, self.h, self.w, self.keep, self.relu_taps = net, batch, height, width, keep, relu_taps
+        assert 0 <= prefix < batch
+        self.prefix, self.nl = prefix, batch - prefix     # nl: samples that carry loss terms
         dev, dt = net.device, net.dtype
         self.style_names = STYLE_RELU_TAPS if relu_taps else STYLE_CONV_TAPS
         self.content_name = CONTENT_RELU_TAP if relu_taps else CONTENT_CONV_TAP
@@ -108,22 +113,25 @@ class VggReplica:
             self._gbuf = [torch.empty(scratch_need, dtype=dt, device=dev) for _ in range(2)]
         else:
             self._scratch = [torch.empty(scratch_need, dtype=dt, device=dev) for _ in range(3)]
-        self.grams = [torch.empty((batch, self.shape[nm][3], self.shape[nm][3]), dtype=torch.float32, device=dev)
+        nl = self.nl
+        lshape = {nm: (nl,) + tuple(sh[1:]) for nm, sh in self.shape.items()}
+        self.grams = [torch.empty((nl, self.shape[nm][3], self.shape[nm][3]), dtype=torch.float32, device=dev)
                       for nm in self.style_names]
         # partial sums of the Gram kernels' pixel slices (folded in a fixed order: no atomics); the five Gram
         # jobs of a pass run in stream order on one stream, so they share one workspace
-        need = max(ops.gram_ws_floats(self.shape[nm], dt) for nm in self.style_names)
+        need = max(ops.gram_ws_floats(lshape[nm], dt) for nm in self.style_names)
         self.gram_ws = torch.empty(max(need, 4), dtype=torch.float32, device=dev)
         self.content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
         if keep:
-            self.s_packed = [torch.empty(ops.gram_packed_elems(batch, self.shape[nm][3]), dtype=dt, device=dev)
+            self.s_packed = [torch.empty(ops.gram_packed_elems(nl, self.shape[nm][3]), dtype=dt, device=dev)
                              for nm in self.style_names]
             # d(style loss)/d(tap) per style layer, written beside the forward chain; the backward
             # chain's data-gradient kernels take it as an addend
-            self.gram_grad = [torch.empty(self.shape[nm], dtype=dt, device=dev) for nm in self.style_names]
-            self.d_content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
-            self.d_image = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
-            self.tv_grad = torch.empty((batch, height, width, 3), dtype=dt, device=dev)
+            self.gram_grad = [torch.empty(lshape[nm], dtype=dt, device=dev) for nm in self.style_names]
+            self.d_content = torch.empty(lshape[self.content_name], dtype=dt, device=dev)
+            self.d_image = torch.empty((nl, height, width, 3), dtype=dt, device=dev)
+            self.tv_grad = torch.empty((nl, height, width, 3), dtype=dt, device=dev)
+            self._lshape = lshape
         # Gram matrices and their loss terms hang off the conv chain as leaves: with kept
         # (dedicated) tap buffers they run on a side stream beside the following layers.
         self._side = torch.cuda.Stream(device=dev) if keep and dev.type == 'cuda' and 'g' not in _SERIAL else None
@@ -228,6 +236,7 @@ class VggReplica:
         self._deferred.clear()
 
     def _gram_job(self, li, tensor):
+        tensor = tensor[self.prefix:]
         ops.gram_fwd(tensor, out=self.grams[li], ws=self.gram_ws)
         if self._style_job is not None:
             self._style_job(li, tensor)
@@ -260,14 +269,17 @@ class VggReplica:
                       content_stream=None):
         """Runs forward on x_f32, leaves the loss terms in `slots` (ops.loss_slots(LOSS_SLOTS): the caller
         turns them into [_, style, content, tv] with ops.loss_slots_sum(slots, LOSS_TERMS, out4)) and returns
-        d(total)/d(x) in the compute dtype.
+        d(total)/d(x) in the compute dtype, for the samples behind the replica's forward-only prefix (with a prefix,
+        content_target must be None: the prefix samples' content tap is the target).
 
         style_targets: 5 fp32 [c,c] (or [1,c,c]) Grams, content_target: tensor shaped like the content tap;
         content_stream: stream that is still producing content_target (joined before its first use)."""
         assert self.keep
-        net, n = self.net, self.n
+        net, n, p0 = self.net, self.nl, self.prefix
+        lead = lambda t: t[p0:]     # the samples that carry loss terms (a contiguous slice of an NHWC batch)
         assert tuple(slots.shape) == (self.LOSS_SLOTS, ops.LOSS_SLOT)
         l_content, l_tv = slots[5], slots[6]
+        x_loss = lead(x_f32)
 
         # style: sum_l mean((G_l - T_l)^2) * w / len(content outputs)   (model_utilities.py:396)
         def style_term(li, tap):
@@ -283,7 +295,7 @@ class VggReplica:
 
         # the TV term needs only the image and its gradient joins at the very end: beside the chain
         def tv():
-            ops.tv_loss_fwd_bwd(x_f32, l_tv, tv_weight, net.dtype, out=self.tv_grad)
+            ops.tv_loss_fwd_bwd(x_loss, l_tv, tv_weight, net.dtype, out=self.tv_grad)
             if self._side is not None:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -313,8 +325,13 @@ class VggReplica:
                 tv()
         if content_stream is not None:
             torch.cuda.current_stream().wait_stream(content_stream)
-        cnt = self.content.numel()
-        ops.mse_fwd_bwd(self.content, content_target, l_content, content_weight / cnt, 2.0 * content_weight / cnt,
+        if p0 > 0:
+            # the forward-only samples in front ARE the content pictures of the samples behind them
+            assert content_target is None and p0 == n
+            content_target = self.content[:p0]
+        content = lead(self.content)
+        cnt = content.numel()
+        ops.mse_fwd_bwd(content, content_target, l_content, content_weight / cnt, 2.0 * content_weight / cnt,
                         out=self.d_content)
 
         # backward through the truncated VGG; g is always the gradient w.r.t. a conv's pre-ReLU output
@@ -328,7 +345,7 @@ class VggReplica:
                 if name in self.style_names and name not in joined:
                     # no masked data-gradient kernel produced g (the tap feeds a pool): add it here
                     join(self.style_names.index(name))
-                    ops.gram_bwd(self.pre[name], self.s_packed[self.style_names.index(name)], g, accumulate=True)
+                    ops.gram_bwd(lead(self.pre[name]), self.s_packed[self.style_names.index(name)], g, accumulate=True)
                 L = net.convs[name]
                 in_name = names[idx - 1] if idx > 0 else None
                 h, w = (self.shape[in_name][1], self.shape[in_name][2]) if in_name else (self.h, self.w)
@@ -339,8 +356,8 @@ class VggReplica:
                     if ci == 3 and ops.to3_supported(k, L.kshape[3], net.dtype) and 'r' not in _SERIAL:
                         ops.conv2d_to3(g, L.wp_bwd_rows, k, addend=self.tv_grad, out=self.d_image)
                     else:
-                        ops.conv2d_fwd(g, L.wp_bwd_rows, (k, 1, L.kshape[3], 32), 1, out=self.rows_gbuf)
-                        ops.rows_to_pixels_sum(self.rows_gbuf, ci, k, -((k - 1) // 2), out=self.d_image,
+                        ops.conv2d_fwd(g, L.wp_bwd_rows, (k, 1, L.kshape[3], 32), 1, out=lead(self.rows_gbuf))
+                        ops.rows_to_pixels_sum(lead(self.rows_gbuf), ci, k, -((k - 1) // 2), out=self.d_image,
                                                addend=self.tv_grad)
                     g = self.d_image
                 elif in_name is None:
@@ -350,23 +367,23 @@ class VggReplica:
                                      out=self.d_image)
                     g = self.d_image
                 elif in_name.startswith('relu'):
-                    dx = self._buf(self._gbuf, self.shape[in_name], (g,))
+                    dx = self._buf(self._gbuf, self._lshape[in_name], (g,))
                     below = names[idx - 2]  # the conv under that ReLU: its Gram gradient joins after the mask
                     addend = None
                     if below in self.style_names and below in self.pre:
                         join(self.style_names.index(below))
                         addend = self.gram_grad[self.style_names.index(below)]
                         joined.add(below)
-                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=self.act[in_name], addend=addend,
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=lead(self.act[in_name]), addend=addend,
                                      out=dx)
                     g = dx
                     idx -= 1  # the ReLU is folded into the mask
                 else:  # pool output feeds this conv
-                    dpool = self._buf(self._gbuf, self.shape[in_name], (g,))
+                    dpool = self._buf(self._gbuf, self._lshape[in_name], (g,))
                     ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), out=dpool)
                     relu_name = names[idx - 2]
-                    dx = self._buf(self._gbuf, self.shape[relu_name], (dpool,))
-                    ops.maxpool_bwd(self.act[relu_name], dpool, out=dx)
+                    dx = self._buf(self._gbuf, self._lshape[relu_name], (dpool,))
+                    ops.maxpool_bwd(lead(self.act[relu_name]), dpool, out=dx)
                     g = dx
                     idx -= 2
             idx -= 1
