@@ -339,6 +339,63 @@ def run_infer(args, dtype_name, steps, warmup, world, rank, device, want_rooflin
     return out
 
 
+def run_infer_host(args, dtype_name, steps, warmup, world, rank, device):
+    """1080p inference INCLUDING the host link: 8-bit frames (as a JPEG decoder leaves them) in pinned host memory
+    -> H2D -> stylizer -> 8-bit frames -> D2H -> pinned host memory, chunks of 16 double-buffered over three
+    streams (stmi.dist.FrameStager), so that transfers run under the kernels.  A step = one chunk.  Also timed,
+    outside the step: JPEG decode / encode of 1080p frames on the box's host threads (stmi.dist.FrameCodecPool)."""
+    from stmi.dist import FrameCodecPool, FrameStager
+    from stmi.stylizer import StylizerNet, init_params
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    rng = np.random.default_rng(1234 + rank)
+    B = args.batch or 16
+    net = StylizerNet(B, 1080, 1920, device, dtype, params=init_params(seed=1))
+    chunks = [rng.integers(0, 256, size=(B, 1080, 1920, 3), dtype=np.uint8) for _ in range(2)]
+    stager = FrameStager((B, 1080, 1920, 3), device, torch.uint8)
+    state = {'k': 0, 'bytes': 0}
+
+    def forward(x, out):
+        net.forward_u8(x, out=out)
+
+    def step():
+        k = state['k']
+        slot = k & 1
+        if k == 0:
+            stager.upload(0, chunks[0])
+        stager.upload(slot ^ 1, chunks[(k + 1) & 1])          # the next chunk crosses the link under this one's kernels
+        stager.run(slot, B, forward)
+        if k >= 1:
+            state['bytes'] += stager.collect(slot ^ 1, B, copy=False).nbytes   # the previous chunk is back on the host
+        state['k'] = k + 1
+
+    secs = timed_steps(step, steps, warmup, world, device)
+    stager.collect((state['k'] - 1) & 1, B, copy=False)
+    out = {'metric': 'stylized img/s @1080p, host-inclusive (8-bit frames over PCIe both ways)', 'unit': 'img/s',
+           'value': round(B * world * steps / secs, 3), 'ms_per_step': round(secs / steps * 1e3, 4), 'scaling': 'weak',
+           'dtype': dtype_name, 'steps': steps,
+           'config': {'workload': 'batched 1920x1080 stylizer inference, %d frames per chunk and GPU, uint8 frames from '
+                      'pinned host memory and back (FrameStager: H2D / compute / D2H streams, double-buffered)' % B,
+                      'global_batch': B * world, 'input': 'pinned host memory, uint8',
+                      'link_mb_per_chunk_each_way': round(B * 1080 * 1920 * 3 / 1e6, 1)}}
+    if rank == 0:
+        # the host codec side, with the core count: one synthetic 1080p picture, decoded / encoded 64 times
+        yy, xx = np.mgrid[0:1080, 0:1920].astype(np.float32)
+        pic = np.stack([127 + 100 * np.sin(0.01 * yy + 0.013 * xx + c) * np.cos(0.004 * xx - c) for c in range(3)], -1)
+        pic = (pic + rng.normal(0, 6, pic.shape)).clip(0, 255).astype(np.uint8)
+        pool = FrameCodecPool()
+        blob = pool.encode([pic])[0]
+        t0 = time.perf_counter()
+        frames = pool.decode([blob] * 64)
+        t1 = time.perf_counter()
+        pool.encode(frames)
+        t2 = time.perf_counter()
+        pool.close()
+        out['host_codec'] = {'threads': pool.workers, 'jpeg_kb_per_frame': round(len(blob) / 1e3, 1),
+                             'decode_frames_per_s': round(64 / (t1 - t0), 1), 'encode_frames_per_s': round(64 / (t2 - t1), 1),
+                             'library': 'PIL (libjpeg) on a thread pool'}
+    return out
+
+
 def run_gatys(args, dtype_name, steps, warmup, world, rank, device, want_roofline):
     from stmi.trainer import GatysOptimizer
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
@@ -396,7 +453,8 @@ def main():
                     help='train, 1 GPU: skip the 1080p-inference, Gatys and fp32-training lines of "secondary"')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--host-input', action='store_true',
-                    help='train: copy the batch from pinned host memory inside every timed step (PCIe-inclusive rate)')
+                    help='train: copy the batch from pinned host memory inside every timed step (PCIe-inclusive rate); '
+                         'infer1080p: 8-bit frames from pinned host memory and back, double-buffered')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -417,6 +475,7 @@ def main():
             # there is reported in place and never costs the headline line
             line['secondary'] = []
             jobs = [('infer1080p', lambda: run_infer(args, 'bf16', 20, 5, world, rank, device, roof)),
+                    ('infer1080p_host', lambda: run_infer_host(args, 'bf16', 20, 5, world, rank, device)),
                     ('gatys', lambda: run_gatys(args, 'bf16', 100, 10, world, rank, device, roof)),
                     ('train_f32', lambda: run_train(args, 'f32', 20, 5, world, rank, device, roof, False))]
             for name, job in jobs:
@@ -430,6 +489,8 @@ def main():
                     line['secondary'].append({'name': name, 'error': repr(exc)})
         if cpu_first is not None and rank == 0 and args.batch is None:
             line['parity_gate'] = parity_gate(cpu_first, gpu_first)
+    elif args.workload == 'infer1080p' and args.host_input:
+        line.update(run_infer_host(args, args.dtype, args.steps, args.warmup, world, rank, device))
     elif args.workload == 'infer1080p':
         line.update(run_infer(args, args.dtype, args.steps, args.warmup, world, rank, device, roof))
     else:

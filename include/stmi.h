@@ -133,6 +133,15 @@ int stmi_conv2d_rgb_nhwc_fwd_tile_stats(const float* x_f32, float scale, const f
                                         void* y, float* tile_stats,
                                         int n, int h, int w, int co, int k, int dtype, void* stream);
 
+/* The stylizer's first layer on 8-BIT frames as a decoder leaves them (image_utilities.py:229-236 divides by 255
+ * on the host; here scale = 1/255 does it while the frame is read, so a frame crosses the host link as 3 bytes a
+ * pixel instead of 12): x_u8 [n,h,w,3] unsigned char -> y [n,h,w,co] = conv(x * scale - mean[c]) in dtype, no bias
+ * or ReLU; W packed with STMI_PACK_FWD_RGB.  tile_stats: NULL, or the per-tile sums described at
+ * stmi_conv2d_rgb_nhwc_fwd_tile_stats.  Built for (k, co) = (9, 32). */
+int stmi_conv2d_rgb_u8_nhwc_fwd(const unsigned char* x_u8, float scale, const float* mean, const void* w_packed_rgb,
+                                void* y, float* tile_stats,
+                                int n, int h, int w, int co, int k, int dtype, void* stream);
+
 /* k x k stride-1 SAME convolution ci -> 3 in one launch (the stylizer's last layer,
  * full_graph_stylizer_network.py:78; with the flipped, transposed kernel it is the backward-data of VGG
  * conv1_1): x [n,h,w,ci] -> y [n,h,w,3] = conv(x) + addend (optional, shaped like y).  W packed with
@@ -261,6 +270,12 @@ int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float
                                   const void* residual, void* y, float* y_f32,
                                   int act, int n, int h, int w, int c,
                                   int dtype, void* stream);
+/* stmi_instance_norm_nhwc_apply for the LAST layer of a service that hands 8-bit frames back: y_u8 [n,h,w,c] =
+ * (unsigned char)(act(scale*xhat + shift) * 255), truncated as the reference's save path does
+ * ((img * 255).astype(uint8), image_utilities.py:195-196, :223-227) and clamped to 0 .. 255.  Built for c = 3. */
+int stmi_instance_norm_nhwc_apply_u8(const void* x, const float* stats, const float* scale, const float* shift,
+                                     unsigned char* y_u8, int act, int n, int h, int w, int c,
+                                     int dtype, void* stream);
 int stmi_instance_norm_nhwc_bwd(const void* x, const void* dy, const float* stats,
                                 const float* scale, const float* shift,
                                 void* dx, float* dscale, float* dshift, int accumulate, float* ws,

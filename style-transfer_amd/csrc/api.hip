@@ -56,6 +56,10 @@ int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void
                       void* y_pre, int n, int h, int w, int co, int k, int relu, int dtype, hipStream_t s,
                       float* tile_stats = nullptr);
 int conv_rgb_tile_stats_tiles(int h, int w, int co, int k);
+int conv_rgb_u8_fwd_impl(const unsigned char* x, float scale, const float* mean, const void* wq, void* y, int n, int h,
+                         int w, int co, int k, int dtype, hipStream_t s, float* tile_stats);
+int in_apply_u8_impl(const void* x, const float* stats, const float* scale, const float* shift, unsigned char* y,
+                     int act, int n, int h, int w, int c, int dtype, hipStream_t s);
 int conv_rgb_dgrad_impl(const void* dy, const void* wq, void* dx, int n, int h, int w, int ci, int k, int dtype,
                         hipStream_t s);
 int conv_to3_supported(int k, int ci, int dtype);
@@ -242,6 +246,16 @@ int stmi_conv2d_rgb_nhwc_fwd_tile_stats(const float* x_f32, float scale, const f
                              tile_stats);
 }
 
+int stmi_conv2d_rgb_u8_nhwc_fwd(const unsigned char* x_u8, float scale, const float* mean, const void* w_packed_rgb,
+                                void* y, float* tile_stats, int n, int h, int w, int co, int k, int dtype, void* stream) {
+    if (check_conv("conv2d_rgb_u8_nhwc_fwd", n, h, w, 3, co, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
+    STMI_REQUIRE(x_u8 && w_packed_rgb && y, "conv2d_rgb_u8_nhwc_fwd: null pointer");
+    STMI_REQUIRE(!tile_stats || conv_rgb_tile_stats_tiles(h, w, co, k) > 0, "conv2d_rgb_u8_nhwc_fwd: no tile statistics "
+                 "for this (k, co) (stmi_conv2d_rgb_tile_stats_tiles returned 0)");
+    return conv_rgb_u8_fwd_impl(x_u8, scale, mean, w_packed_rgb, y, n, h, w, co, k, dtype, S(stream), tile_stats);
+}
+
 int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, void* dx, int n, int h, int w, int ci,
                                int k, int dtype, void* stream) {
     if (check_conv("conv2d_rgb_nhwc_dgrad", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
@@ -387,6 +401,15 @@ int stmi_instance_norm_nhwc_apply(const void* x, const float* stats, const float
     STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_apply: bad activation %d", act);
     if (n == 0) return STMI_OK;
     return in_apply_impl(x, stats, scale, shift, residual, y, y_f32, act, n, h, w, c, dtype, S(stream));
+}
+
+int stmi_instance_norm_nhwc_apply_u8(const void* x, const float* stats, const float* scale, const float* shift,
+                                     unsigned char* y_u8, int act, int n, int h, int w, int c, int dtype, void* stream) {
+    if (check_dtype(dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && stats && scale && shift && y_u8 && n >= 0 && h > 0 && w > 0 && c > 0, "instance_norm_nhwc_apply_u8: bad arguments");
+    STMI_REQUIRE(act >= STMI_ACT_NONE && act <= STMI_ACT_SIGMOID, "instance_norm_nhwc_apply_u8: bad activation %d", act);
+    if (n == 0) return STMI_OK;
+    return in_apply_u8_impl(x, stats, scale, shift, y_u8, act, n, h, w, c, dtype, S(stream));
 }
 
 int stmi_instance_norm_nhwc_fwd(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,

@@ -69,6 +69,7 @@ int ensure_dynamic_lds(const void* fn, int bytes, const char* what, std::atomic<
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<unsigned char>(unsigned char v) { return (float)v; }
 
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }

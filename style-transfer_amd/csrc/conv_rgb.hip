@@ -23,8 +23,9 @@ namespace {
 constexpr int kRgbPH = 8, kRgbPW = 32;  // output pixels per block: 4 waves x (2 rows x 32)
 }
 
-// XT: element type of the image, float (forward layers) or T (backward-data of a layer that WRITES 3
-// channels: its input gradient is this same convolution of dy with the flipped, transposed kernel).
+// XT: element type of the image: float (forward layers), unsigned char (8-bit frames straight from a decoder:
+// x / 255 is `scale`), or T (backward-data of a layer that WRITES 3 channels: its input gradient is this same
+// convolution of dy with the flipped, transposed kernel).
 // STATS: the block also leaves the per-tile sums of its output (ConvGemmParams::tile_stats, mode 1; one row per
 // block) for the instance norm behind the stylizer's first layer.  That form has its own epilogue: a wave
 // stages its 2 x 32 pixels as [64][CO] rows of T, stores them as whole rows and takes the sums from the staged
@@ -224,7 +225,7 @@ static int launch_rgb(const XT* x, float scale, const float* mean, const void* w
     {
         char name[160];
         const char* tn = sizeof(T) == 2 ? "__bf16" : "float";
-        const char* xn = sizeof(XT) == 2 ? "__bf16" : "float";
+        const char* xn = sizeof(XT) == 1 ? "unsigned char" : (sizeof(XT) == 2 ? "__bf16" : "float");
         snprintf(name, sizeof(name), "void stmi::conv_rgb_kernel<%s, %d, %d, %s, %s>(%s const*, float, float const*, %s const*, stmi::ConvGemmParams)",
                  tn, K, TC, xn, STATS ? "true" : "false", xn, tn);
         set_last_conv_kernel(name);
@@ -267,6 +268,27 @@ int conv_rgb_fwd_impl(const float* x, float scale, const float* mean, const void
     if (k == 3 && co == 32) return bf ? launch_rgb<bf16_t, 3, 2, float>(x, scale, mean, wq, p, s) : launch_rgb<float, 3, 2, float>(x, scale, mean, wq, p, s);
     set_error("conv_rgb: unsupported (k, co) = (%d, %d); built for (9, 32), (3, 64) and (3, 32)", k, co);
     return STMI_ERR_INVALID;
+}
+
+// The plain (9, 32) layer on 8-bit frames [n,h,w,3]: conv(x * scale - mean) computed in dtype; tile_stats optional.
+int conv_rgb_u8_fwd_impl(const unsigned char* x, float scale, const float* mean, const void* wq, void* y, int n, int h,
+                         int w, int co, int k, int dtype, hipStream_t s, float* tile_stats) {
+    ConvGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.out = y; p.alpha = 1.f;
+    p.tile_stats = tile_stats; p.tile_stats_mode = tile_stats ? 1 : 0;
+    p.N = n; p.Hi = h; p.Wi = w; p.Ci = 3;
+    p.Ho = h; p.Wo = w; p.Co = co;
+    STMI_REQUIRE((((uintptr_t)y | (uintptr_t)wq) & 15) == 0, "conv_rgb: y and the packed weights must be 16-byte aligned");
+    STMI_REQUIRE((long)n * h * w * 3 < (1L << 31), "conv_rgb: image batch too large for 32-bit indexing");
+    STMI_REQUIRE(k == 9 && co == 32, "conv_rgb (8-bit frames): built for the (9, 32) layer, got (%d, %d)", k, co);
+    p.row_store_ok = 1;
+    const bool bf = dtype == STMI_BF16;
+    if (tile_stats)
+        return bf ? launch_rgb<bf16_t, 9, 2, unsigned char, true>(x, scale, mean, wq, p, s)
+                  : launch_rgb<float, 9, 2, unsigned char, true>(x, scale, mean, wq, p, s);
+    return bf ? launch_rgb<bf16_t, 9, 2, unsigned char>(x, scale, mean, wq, p, s)
+              : launch_rgb<float, 9, 2, unsigned char>(x, scale, mean, wq, p, s);
 }
 
 // Backward-data of a k x k stride-1 SAME convolution ci -> 3 (the stylizer's last layer,

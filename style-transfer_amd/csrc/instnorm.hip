@@ -420,6 +420,71 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// The last layer's apply pass for callers that want 8-bit frames: y_u8 = (unsigned char)(act(a x + b) * 255),
+// truncated like the reference's (img * 255).astype(uint8) (image_utilities.py:195-196), clamped to 0 .. 255.
+// A thread owns PX consecutive pixels of C channels (3 channels: 4 pixels = 24 bytes of bf16 in, 12 bytes out).
+template <typename T, int C, int PX>
+__global__ __launch_bounds__(256) void in_apply_u8_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          unsigned char* __restrict__ y, int act, int HW, long groups) {
+    const long gidx = blockIdx.x * 256L + threadIdx.x;
+    if (gidx >= groups) return;
+    const int gps = (HW + PX - 1) / PX;                 // pixel groups per sample (the last one may be short)
+    const int n = (int)(gidx / gps);
+    const int pix0 = (int)(gidx - (long)n * gps) * PX;
+    float a[C], b[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float mean = stats[((long)n * C + c) * 2], rstd = stats[((long)n * C + c) * 2 + 1];
+        a[c] = scale[c] * rstd;
+        b[c] = shift[c] - mean * a[c];
+    }
+    const long base = ((long)n * HW + pix0) * C;
+    const bool whole = pix0 + PX <= HW;
+    float v[PX * C];
+    if (whole && (((uintptr_t)(x + base)) & 7) == 0 && (PX * C * sizeof(T)) % 8 == 0) {
+        constexpr int NW = PX * C * (int)sizeof(T) / 8;
+        uint2 raw[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) raw[q] = reinterpret_cast<const uint2*>(x + base)[q];
+        const T* e = reinterpret_cast<const T*>(raw);
+#pragma unroll
+        for (int i = 0; i < PX * C; i++) v[i] = to_f32<T>(e[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PX * C; i++) v[i] = pix0 + i / C < HW ? to_f32<T>(x[base + i]) : 0.f;
+    }
+    unsigned char out[PX * C];
+#pragma unroll
+    for (int i = 0; i < PX * C; i++) {
+        const float z = act_fwd(a[i % C] * v[i] + b[i % C], act) * 255.f;
+        out[i] = (unsigned char)fminf(fmaxf(z, 0.f), 255.f);
+    }
+    if (whole && (((uintptr_t)(y + base)) & 3) == 0 && (PX * C) % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < PX * C / 4; q++) reinterpret_cast<unsigned int*>(y + base)[q] = reinterpret_cast<const unsigned int*>(out)[q];
+    } else {
+#pragma unroll
+        for (int i = 0; i < PX * C; i++)
+            if (pix0 + i / C < HW) y[base + i] = out[i];
+    }
+}
+
+int in_apply_u8_impl(const void* x, const float* stats, const float* scale, const float* shift, unsigned char* y,
+                     int act, int n, int h, int w, int c, int dtype, hipStream_t s) {
+    STMI_REQUIRE(c == 3, "instance norm apply to 8-bit frames: built for 3-channel images (c=%d)", c);
+    constexpr int PX = 4;
+    const int HW = h * w;
+    const long groups = (long)n * ((HW + PX - 1) / PX);
+    const dim3 grid((unsigned)((groups + 255) / 256));
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL((in_apply_u8_kernel<bf16_t, 3, PX>), grid, dim3(256), 0, s, (const bf16_t*)x, stats, scale, shift, y, act, HW, groups);
+    else
+        hipLaunchKernelGGL((in_apply_u8_kernel<float, 3, PX>), grid, dim3(256), 0, s, (const float*)x, stats, scale, shift, y, act, HW, groups);
+    STMI_LAUNCH_CHECK("in_apply_u8_kernel");
+    return STMI_OK;
+}
+
 // backward pass 1: per-(n,c) sums of g and g*xhat, g = dy * act'(z)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,

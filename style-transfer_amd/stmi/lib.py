@@ -34,6 +34,7 @@ SIGNATURES = {
     'stmi_conv2d_rgb_nhwc_fwd': (_c_int, [_vp, _c_float] + [_vp] * 5 + [_c_int] * 7 + [_vp]),
     'stmi_conv2d_rgb_tile_stats_tiles': (_c_int, [_c_int] * 4),
     'stmi_conv2d_rgb_nhwc_fwd_tile_stats': (_c_int, [_vp, _c_float] + [_vp] * 4 + [_c_int] * 6 + [_vp]),
+    'stmi_conv2d_rgb_u8_nhwc_fwd': (_c_int, [_vp, _c_float] + [_vp] * 4 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_rgb_nhwc_dgrad': (_c_int, [_vp] * 3 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_to3_supported': (_c_int, [_c_int] * 3),
     'stmi_conv2d_to3_nhwc_fwd': (_c_int, [_vp] * 4 + [_c_int] * 6 + [_vp]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'stmi_instance_norm_nhwc_stats': (_c_int, [_vp, _vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_stats_static': (_c_int, [_vp, _vp, _c_float] + [_c_int] * 5 + [_vp]),
     'stmi_instance_norm_nhwc_apply': (_c_int, [_vp] * 7 + [_c_int] * 6 + [_vp]),
+    'stmi_instance_norm_nhwc_apply_u8': (_c_int, [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_fwd': (_c_int, [_vp, _vp, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_apply_tiles': (_c_int, [_vp, _vp, _c_int, _vp, _c_float] + [_vp] * 5 + [_c_int] * 6 + [_vp]),
     'stmi_instance_norm_nhwc_bwd': (_c_int, [_vp] * 8 + [_c_int, _vp, _c_float] + [_c_int] * 6 + [_vp]),

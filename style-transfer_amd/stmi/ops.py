@@ -198,6 +198,24 @@ def conv2d_rgb_fwd(x_f32, w_packed, k, co, dtype, scale=1.0, mean=None, bias=Non
     return (y, pre) if want_pre else y
 
 
+def conv2d_rgb_u8_fwd(x_u8, w_packed, k, co, dtype, scale=1.0 / 255.0, mean=None, out=None, tile_stats=None):
+    """conv2d_rgb_fwd on 8-bit frames [n,h,w,3] (torch.uint8): conv(x * scale - mean[c]) in `dtype`; plain
+    convolution (no bias / ReLU), built for (k, co) = (9, 32).  tile_stats as for conv2d_rgb_fwd."""
+    n, h, w, c = x_u8.shape
+    assert c == 3 and (k, co) == RGB_CONFIGS[0], (c, k, co)
+    _chk(x_u8, 'x_u8', torch.uint8)
+    _chk(w_packed, 'w_packed', dtype, (packed_elems(k, k, 3, co, PACK_FWD_RGB),))
+    oshape = (n, h, w, co)
+    y = torch.empty(oshape, dtype=dtype, device=x_u8.device) if out is None else _chk(out, 'out', dtype, oshape)
+    if mean is not None:
+        _chk(mean, 'mean', torch.float32, (3,))
+    if tile_stats is not None:
+        _chk(tile_stats, 'tile_stats', torch.float32, (n, conv_rgb_tile_stats_tiles(h, w, co, k), 4, co))
+    _conv_call('stmi_conv2d_rgb_u8_nhwc_fwd', (x_u8.data_ptr(), float(scale), _ptr(mean), w_packed.data_ptr(), y.data_ptr(),
+                                               _ptr(tile_stats), n, h, w, co, k, _dt(y)), co, n * h * w, 3, k * k, 1)
+    return y
+
+
 def to3_supported(k, ci, dtype):
     return bool(_lib.load().stmi_conv2d_to3_supported(k, ci, _DT[dtype]))
 
@@ -448,6 +466,34 @@ def instance_norm_fwd(x, scale, shift, act=ACT_NONE, residual=None, want_f32=Fal
         nbytes = x.numel() * x.element_size() * (2 + (residual is not None)) + (0 if y32 is None else 4 * x.numel())
         PROFILE_HBM.append(('instance_norm_fwd', nbytes, launch))
     return (y, stats, y32) if want_f32 else (y, stats)
+
+
+def instance_norm_stats(x, ws=None, stats=None, eps=IN_EPS):
+    """stats [n,c,2] = (mean, 1/sqrt(var+eps)) of x, as a pass of its own."""
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    if ws is None:
+        ws = instance_norm_ws(n, h, w, c, x.device)
+    if stats is None:
+        stats = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    _chk(stats, 'stats', torch.float32, (n, c, 2))
+    _lib.call('stmi_instance_norm_nhwc_stats', x.data_ptr(), ws.data_ptr(), stats.data_ptr(), float(eps), n, h, w, c,
+              _dt(x), _stream())
+    return stats
+
+
+def instance_norm_apply_u8(x, stats, scale, shift, act=ACT_NONE, out=None):
+    """The 3-channel last layer's apply pass straight to 8-bit frames: (uint8)(act(scale*xhat + shift) * 255),
+    truncated like the reference's (img * 255).astype(uint8)."""
+    n, h, w, c = x.shape
+    _chk(x, 'x')
+    _chk(stats, 'stats', torch.float32, (n, c, 2))
+    _chk(scale, 'scale', torch.float32, (c,))
+    _chk(shift, 'shift', torch.float32, (c,))
+    y = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if out is None else _chk(out, 'out', torch.uint8, x.shape)
+    _lib.call('stmi_instance_norm_nhwc_apply_u8', x.data_ptr(), stats.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              y.data_ptr(), act, n, h, w, c, _dt(x), _stream())
+    return y
 
 
 def instance_norm_bwd_rows_count(x_shape, dtype):

@@ -54,6 +54,14 @@ def init_params(seed=1, cin=3):
     return out
 
 
+def stylized_size(height, width):
+    """Output size of the stylizer for an input of height x width: two stride-2 SAME convolutions (ceil) and two
+    transposed convolutions that double exactly (full_graph_stylizer_network.py:62-71) -- the input size when it
+    is a multiple of 4, the next multiple of 4 otherwise."""
+    f = lambda v: -(-(-(-v // 2)) // 2) * 4
+    return f(height), f(width)
+
+
 class _Block:
     pass
 
@@ -230,9 +238,25 @@ class StylizerNet:
         n = self.n * b.out_h * b.out_w * b.co
         return buf[:n].view(self.n, b.out_h, b.out_w, b.co)
 
+    def forward_u8(self, x_u8, out=None):
+        """8-bit frames in, 8-bit frames out (inference executors): x_u8 [n,h,w,3] torch.uint8 as a decoder
+        leaves them -> uint8 [n,h,w,3] = (stylized * 255) truncated, what the reference's save_image writes
+        (image_utilities.py:195-196, :223-236).  The division by 255 happens while the first layer reads the
+        frame, the conversion back in the last layer's normalisation pass: a frame crosses the host link as
+        3 bytes a pixel each way."""
+        assert not self.training and self.blocks[0].rgb, 'the 8-bit path is built on the 3-channel first-layer kernel'
+        if out is None:
+            out = torch.empty((self.n,) + stylized_size(self.h, self.w) + (3,), dtype=torch.uint8, device=x_u8.device)
+        self._forward(x_u8, out_u8=out)
+        return out
+
     def forward(self, x_f32):
         """x_f32 [n,h,w,3] fp32 in [0,1] -> fp32 [n,h,w,3] (also kept as self.out_f32)."""
+        return self._forward(x_f32)
+
+    def _forward(self, x_f32, out_u8=None):
         self._x_f32 = x_f32
+        u8_in = x_f32.dtype == torch.uint8
         if not self.blocks[0].rgb:
             ops.cast(x_f32, self.dtype, out=self.x_in) if self.dtype != torch.float32 else self.x_in.copy_(x_f32)
         b0 = self.blocks[0]
@@ -258,6 +282,8 @@ class StylizerNet:
                 conv_out, y = self._view(free[0], b), self._view(free[1], b)
             if b.kind == 'deconv':
                 ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
+            elif b.rgb and u8_in:
+                ops.conv2d_rgb_u8_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out, tile_stats=b.tile_stats)
             elif b.rgb:
                 ops.conv2d_rgb_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out, tile_stats=b.tile_stats)
             elif b.rows == 'in':
@@ -272,6 +298,10 @@ class StylizerNet:
                 ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             if b.role == 'a':
                 skip = cur
+            if i == last and out_u8 is not None:
+                ops.instance_norm_stats(conv_out, ws=self.ws, stats=b.stats)
+                ops.instance_norm_apply_u8(conv_out, b.stats, b.scale, b.shift, b.act, out=out_u8)
+                return out_u8
             ops.instance_norm_fwd(conv_out, b.scale, b.shift, b.act, residual=skip if b.role == 'b' else None,
                                   want_f32=(i == last), ws=self.ws, out=y, stats=b.stats,
                                   out_f32=self.out_f32 if i == last else None, tile_stats=b.tile_stats)

@@ -287,3 +287,19 @@ def test_service_loads_without_a_gpu_and_says_so_at_first_use(tmp_path):
         with pytest.raises(RuntimeError, match='no MI355X visible'):
             svc.run_on_image(np.zeros((1, 8, 8, 3), np.float32))
     svc.close()
+
+
+def test_frame_codec_pool_round_trip():
+    """Host side of the frame service: JPEG decode / encode on a thread pool, results in input order."""
+    from stmi.dist import FrameCodecPool
+    yy, xx = np.mgrid[0:48, 0:64].astype(np.float32)
+    frames = [np.stack([127 + 100 * np.sin(0.05 * (k + 1) * yy + 0.08 * xx + c) for c in range(3)], -1).astype(np.uint8)
+              for k in range(5)]
+    pool = FrameCodecPool(workers=3)
+    blobs = pool.encode(frames)
+    back = pool.decode(blobs)
+    pool.close()
+    assert len(back) == 5
+    for a, b in zip(frames, back):
+        assert b.shape == a.shape and b.dtype == np.uint8
+        assert np.abs(a.astype(np.int32) - b.astype(np.int32)).mean() <= 3.0     # JPEG, quality 95

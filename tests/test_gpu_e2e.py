@@ -437,19 +437,49 @@ def test_inference_1080p_batch16_bf16(cuda):
     assert psnr(batch_out[1:2], ref) >= 40.0
 
 
-def test_sharded_frames_match_unsharded(cuda):
-    """stylize_frames_sharded (frames split over ranks, no collective; pinned double-buffered staging):
-    one rank's result equals a plain forward over the same frames, for a frame count that leaves a
-    ragged last chunk."""
+def test_sharded_frames_against_the_oracle(cuda):
+    """stylize_frames_sharded (frames split over ranks, no collective; pinned double-buffered staging) against the
+    ORACLE, for a frame count that leaves a ragged last chunk: float32 frames in fp32 mode to 1e-3; 8-bit frames
+    (as a decoder leaves them) come back as 8-bit frames equal to the oracle's (stylized * 255) truncated
+    (image_utilities.py:195-196) up to one count at a truncation boundary; bf16 mode to 40 dB."""
     from stmi import dist as sd
-    from stmi.stylizer import StylizerNet
     params = O.init_stylizer_params(seed=2)
-    frames = np.random.default_rng(3).random((7, 40, 56, 3)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    frames = rng.random((7, 40, 56, 3)).astype(np.float32)
+    P = [t64(p) for p in params]
+    want = O.stylizer_forward(t64(frames), P)
     idx, got = sd.stylize_frames_sharded(frames, params, dtype=torch.float32, batch=3)
-    assert list(idx) == list(range(7)) and got.shape == frames.shape
-    net = StylizerNet(7, 40, 56, cuda, torch.float32, params=params)
-    want = net.forward(torch.tensor(frames, device=cuda)).cpu().numpy()
-    assert np.array_equal(got, want)
+    assert list(idx) == list(range(7)) and got.shape == frames.shape and got.dtype == np.float32
+    assert rel_err(got, want) <= 1e-3
+    # 8-bit frames: x / 255 happens in the first layer, * 255 and truncation in the last one
+    frames_u8 = rng.integers(0, 256, size=(7, 40, 56, 3), dtype=np.uint8)
+    want_f = O.stylizer_forward(t64(frames_u8) / 255.0, P)
+    want_u8 = (want_f * 255.0).floor().clamp(0, 255)
+    idx, got_u8 = sd.stylize_frames_sharded(frames_u8, params, dtype=torch.float32, batch=3)
+    assert got_u8.dtype == np.uint8 and got_u8.shape == frames_u8.shape
+    diff = (t64(got_u8.astype(np.float64)) - want_u8).abs()
+    assert diff.max().item() <= 1.0 and (diff > 0).double().mean().item() <= 2e-3, (diff.max().item(), (diff > 0).double().mean().item())
+    idx, got_b16 = sd.stylize_frames_sharded(frames_u8, params, dtype=torch.bfloat16, batch=4)
+    assert psnr(t64(got_b16.astype(np.float64)) / 255.0, want_f) >= 40.0
     # the shards of a 3-rank job tile the frame range
     parts = [sd.shard_frames(7, r, 3) for r in range(3)]
     assert [len(p) for p in parts] == [3, 2, 2] and sum((list(p) for p in parts), []) == list(range(7))
+
+
+def test_eight_bit_frames_equal_the_float_path(cuda):
+    """forward_u8 on 8-bit frames = forward on the same frames / 255, then (x * 255) truncated: the two first-layer
+    kernels see the same values (k / 255 rounded to fp32 either way), so the stylized pictures agree to a count
+    where the float result sits on a truncation boundary.  Odd sizes: tiles clipped at both borders; the stylized
+    picture is the next multiple of 4 in size (two stride-2 layers, two exact doublings)."""
+    from stmi.stylizer import StylizerNet
+    params = O.init_stylizer_params(seed=4)
+    rng = np.random.default_rng(9)
+    for (n, h, w), dtype in (((2, 37, 45), torch.float32), ((1, 50, 33), torch.bfloat16)):
+        x8 = torch.tensor(rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8), device=cuda)
+        net = StylizerNet(n, h, w, cuda, dtype, params=params)
+        y8 = net.forward_u8(x8).clone()
+        assert tuple(y8.shape) == (n, -(-h // 4) * 4, -(-w // 4) * 4, 3)
+        yf = net.forward(x8.float() / 255.0)
+        want = (yf * 255.0).floor().clamp(0, 255)
+        diff = (y8.float() - want).abs()
+        assert diff.max().item() <= 1.0 and (diff > 0).float().mean().item() <= 1e-2
