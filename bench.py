@@ -64,6 +64,8 @@ def dist_setup(gpus):
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        assert dist.get_world_size() == gpus, ('--gpus %d but the process group has %d ranks: start one rank per GPU '
+                                               '(torchrun --nproc-per-node %d)' % (gpus, dist.get_world_size(), gpus))
     return world, rank, torch.device('cuda', local)
 
 
@@ -306,7 +308,8 @@ def run_train(args, dtype_name, steps, warmup, world, rank, device, want_rooflin
            'final_losses': {'total': float(losses[0]), 'style': float(losses[1]),
                             'content': float(losses[2]), 'tv': float(losses[3])}}
     if world > 1 and tr.buckets is not None:
-        out['config']['allreduce'] = tr.comm_report()
+        import torch.distributed as dist
+        out['config']['allreduce'] = dict(tr.comm_report(), world_size=dist.get_world_size(), backend=dist.get_backend())
     if rank == 0 and world == 1:
         if want_roofline:
             def eager():

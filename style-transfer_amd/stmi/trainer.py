@@ -68,6 +68,7 @@ class GradBuckets:
             assert a1 == b0, 'gradient buckets must tile the flat buffer'
         self._pending = {}
         self.issue_seconds, self.issued = 0.0, 0
+        self.replay_seconds, self.replays, self.steps = 0.0, 0, 0   # host time inside graph.replay() (filled by the trainer)
 
     def reduce_bucket(self, i):
         import time
@@ -98,9 +99,16 @@ class GradBuckets:
         """Bucket sizes and the host-side cost of issuing one collective (what sits on the step's critical
         path between two graph replays)."""
         mb = [round((e - s) * 4 / 1e6, 3) for s, e in self.ranges]
-        return {'bucket_mb': mb, 'exposed_mb': mb[-1], 'overlapped_mb': round(sum(mb[:-1]), 3),
-                'collectives_issued': self.issued,
-                'host_issue_us_per_collective': round(self.issue_seconds / max(1, self.issued) * 1e6, 1)}
+        out = {'bucket_mb': mb, 'exposed_mb': mb[-1], 'overlapped_mb': round(sum(mb[:-1]), 3),
+               'collectives_issued': self.issued,
+               'host_issue_us_per_collective': round(self.issue_seconds / max(1, self.issued) * 1e6, 1)}
+        if self.replays:
+            # what the HOST spends per step between the device's segments: if this approaches the step time, the
+            # host (not the GPU or the links) paces a data-parallel step
+            out['graph_segments_per_step'] = self.replays // max(1, self.steps)
+            out['host_replay_us_per_segment'] = round(self.replay_seconds / self.replays * 1e6, 1)
+            out['host_us_per_step'] = round((self.replay_seconds + self.issue_seconds) / max(1, self.steps) * 1e6, 1)
+        return out
 
 
 class StyleTrainer:
@@ -298,10 +306,15 @@ class StyleTrainer:
         if self.buckets is None:
             self._graphs[0].replay()
         else:
+            import time
             for i, g in enumerate(self._graphs):
                 self._before(i)
+                t0 = time.perf_counter()
                 g.replay()
+                self.buckets.replay_seconds += time.perf_counter() - t0
+                self.buckets.replays += 1
                 self._between(i)
+            self.buckets.steps += 1
 
     def read_losses(self):
         """[total, style, content, tv] of the last step (synchronises)."""
