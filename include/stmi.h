@@ -88,8 +88,17 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
  * + tf.nn.relu                                     (vgg.py:48, :98)
  * x [n,h,w,ci] -> y [n,ceil(h/s),ceil(w/s),co].  bias may be NULL.  If y_pre is
  * not NULL it receives the value before the ReLU (the pre-ReLU VGG taps of
- * vgg.py:104-105). */
+ * vgg.py:104-105).
+ * ws / ws_floats: optional fp32 workspace (16-byte aligned; NULL / 0: none).  A 3x3 stride-1 layer whose output has
+ * too few tiles to fill the chip (VGG conv5_x on 16 x 16 maps: 64 tiles of 144 K steps for 256 CUs) then splits
+ * its K loop over several blocks per tile: every slice leaves raw fp32 sums in a plane of the workspace and a second
+ * launch of the same call adds the planes in slice order and applies bias / ReLU / copies.  Results differ from the
+ * unsplit launch only in the order of fp32 additions and are bit-reproducible.  stmi_conv2d_ksplit_ws_floats gives
+ * the floats with which a geometry splits (0: it never does; dgrad != 0 asks for stmi_conv2d_nhwc_dgrad); a smaller
+ * workspace means fewer slices or none, never an error. */
+long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
 int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
+                         float* ws, long ws_floats,
                          int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                          int relu, int dtype, void* stream);
 /* The same convolution (model_utilities.py:236-237) that also leaves per-tile sums of what it wrote, from
@@ -162,9 +171,10 @@ int stmi_conv2d_rgb_nhwc_dgrad(const void* dy, const void* w_packed_dgrad_rgb, v
  * for the ops at model_utilities.py:237 and :164):
  *   dx = alpha * backprop_input(dy) ; dx = 0 where relu_mask <= 0 ; dx += addend.
  * dy [n,ho,wo,co] -> dx [n,h,w,ci].  relu_mask and addend are optional tensors
- * shaped like dx (addend may alias dx). */
+ * shaped like dx (addend may alias dx).  ws / ws_floats: optional split-K workspace as at stmi_conv2d_nhwc_fwd. */
 int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx,
                            const void* relu_mask, const void* addend, float alpha,
+                           float* ws, long ws_floats,
                            int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                            int dtype, void* stream);
 

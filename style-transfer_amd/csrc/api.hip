@@ -43,10 +43,12 @@ int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats,
                         int c, int dtype, hipStream_t s);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s,
-                  float* tile_stats = nullptr, int tile_stats_ts = 0);
+                  float* tile_stats = nullptr, int tile_stats_ts = 0, float* ws = nullptr, long ws_floats = 0);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
-                    const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0);
+                    const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0,
+                    float* ws = nullptr, long ws_floats = 0);
+long conv_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
 int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int in_bwd_rows_impl(const void* x, const void* dy, const float* stats, const float* scale, const float* shift, void* dx,
@@ -188,11 +190,21 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
     return pack_weights_multi_impl(src_base, dst_base, descs, n, dtype, S(stream));
 }
 
-int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre, int n,
-                         int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, void* stream) {
+int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
+                         float* ws, long ws_floats, int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                         int relu, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_fwd", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(x && w_packed_fwd && y, "conv2d_nhwc_fwd: null pointer");
-    return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream));
+    STMI_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || (ws && (((uintptr_t)ws) & 15) == 0)),
+                 "conv2d_nhwc_fwd: the workspace must be 16-byte aligned");
+    return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream),
+                         nullptr, 0, ws, ws_floats);
+}
+
+long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    if (dtype != STMI_F32 && dtype != STMI_BF16) return 0;
+    return conv_ksplit_ws_floats(n, h, w, ci, co, kh, kw, stride, dtype, dgrad);
 }
 
 int stmi_conv2d_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
@@ -275,11 +287,14 @@ int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const v
 }
 
 int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,
-                           const void* addend, float alpha, int n, int h, int w, int ci, int co, int kh, int kw,
-                           int stride, int dtype, void* stream) {
+                           const void* addend, float alpha, float* ws, long ws_floats, int n, int h, int w, int ci,
+                           int co, int kh, int kw, int stride, int dtype, void* stream) {
     if (check_conv("conv2d_nhwc_dgrad", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     STMI_REQUIRE(dy && w_packed_dgrad && dx, "conv2d_nhwc_dgrad: null pointer");
-    return conv_dgrad_impl(dy, w_packed_dgrad, dx, relu_mask, addend, alpha, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
+    STMI_REQUIRE(ws_floats >= 0 && (ws_floats == 0 || (ws && (((uintptr_t)ws) & 15) == 0)),
+                 "conv2d_nhwc_dgrad: the workspace must be 16-byte aligned");
+    return conv_dgrad_impl(dy, w_packed_dgrad, dx, relu_mask, addend, alpha, n, h, w, ci, co, kh, kw, stride, dtype, S(stream),
+                           nullptr, nullptr, 0, ws, ws_floats);
 }
 
 int stmi_conv2d_dgrad_in_sums_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {

@@ -457,14 +457,27 @@ static void clear_params(ConvGemmParams& p) {
 
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype,
-                  hipStream_t s, float* tile_stats, int tile_stats_ts) {
+                  hipStream_t s, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats) {
     ConvGemmParams p;
     clear_params(p);
     int rc = setup_fwd(p, n, h, w, ci, co, kh, kw, stride);
     if (rc) return rc;
     p.in = x; p.wp = wp; p.out = y; p.out_pre = y_pre; p.bias = bias; p.addend = addend; p.relu = relu;
     p.tile_stats = tile_stats; p.tile_stats_ts = tile_stats_ts; p.tile_stats_mode = tile_stats ? 1 : 0;
+    p.ksplit_ws = ws_floats > 0 ? ws : nullptr; p.ksplit_ws_floats = ws_floats;
     return launch_conv_gemm(p, dtype, s);
+}
+
+// Floats of workspace with which a forward (dgrad == 0) or stride-1 backward-data (dgrad != 0) convolution of this
+// geometry splits its K loop over several blocks per tile; 0: it never does.  Assumes 16-byte aligned tensors.
+long conv_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad) {
+    if (stride != 1 || kh != 3 || kw != 3) return 0;
+    ConvGemmParams p;
+    clear_params(p);
+    // backward-data of a 3x3 stride-1 layer is the same gather with the roles of ci and co exchanged
+    if (setup_fwd(p, n, h, w, dgrad ? co : ci, dgrad ? ci : co, kh, kw, stride)) return 0;
+    p.row_store_ok = (dgrad ? ci : co) % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    return conv_patch_ksplit_ws_floats(p, dtype);
 }
 
 static int tile_stats_rows(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int mode);
@@ -546,7 +559,7 @@ static bool build_multi_class(const ConvGemmParams& p, int h, int w, int kh, int
 // convolution also leaves the per-tile sums of dx for the instance norm behind it.
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
-                    const InBwdSums* bn, float* tile_stats, int tile_stats_ts) {
+                    const InBwdSums* bn, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats) {
     int ho, wo, pt, pl;
     same_pads(h, kh, stride, &ho, &pt);
     same_pads(w, kw, stride, &wo, &pl);
@@ -577,6 +590,7 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
             p.bn_x = bn->x; p.bn_stats = bn->stats; p.bn_scale = bn->scale; p.bn_shift = bn->shift; p.bn_act = bn->act;
         }
         STMI_REQUIRE(!tile_stats, "conv dgrad: forward tile statistics are for the strided (transposed-conv) form");
+        p.ksplit_ws = ws_floats > 0 && !bn ? ws : nullptr; p.ksplit_ws_floats = ws_floats;
         return launch_conv_gemm(p, dtype, s);
     }
     STMI_REQUIRE(!bn, "conv dgrad: instance-norm sums are produced by stride-1 layers only");

@@ -24,6 +24,15 @@ struct ConvGemmParams {
     unsigned pt_div[3], pt_magic[3];  // patch kernel: channel tiles, tiles per row, tile rows per image (+ reciprocals)
     unsigned pt_npers;                // persistent patch kernel: tiles of the launch
     int pt_wepi;                      // one-tile patch kernel: the MFMA waves finish the tile among themselves
+    // Split K (one-tile patch kernel, layers with too few tiles to fill the chip): pt_ksplit > 1 slices of
+    // pt_kchunks channel chunks each; slice s of a tile leaves its raw fp32 sums in plane s of ksplit_ws
+    // (ksplit_plane floats apart, laid out like the written tensor) and conv_ksplit_fold adds the planes in slice
+    // order and applies bias, alpha, mask, addend, pre-activation copy and ReLU.  ksplit_ws / ksplit_ws_floats:
+    // the caller's workspace (nullptr: never split).
+    int pt_ksplit, pt_kchunks;
+    long ksplit_plane;
+    float* ksplit_ws;
+    long ksplit_ws_floats;
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the
@@ -197,7 +206,8 @@ __device__ __forceinline__ float conv_act_grad(float z, int act) {
 template <typename T, int TC, int TP, int WC, int WP, int NT, int TPG, bool LDSB = false, typename PixelOffset>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const f32x4 (&acc)[TC][TP], int co0,
                                                   float* stage, PixelOffset pixel_offset,
-                                                  TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0, 0, nullptr}) {
+                                                  TileStatsOut ts_out = TileStatsOut{nullptr, 0, 0, 0, nullptr},
+                                                  float* raw_out = nullptr) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BLK_CO = 16 * TC * WC;
     constexpr int STRIDE = BLK_CO + 4;   // floats; +16 bytes keeps the 16-byte writes conflict-free
@@ -263,6 +273,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
             for (int u = 0; u < EPC; u += 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(stage + rr * STRIDE + cl_rd + u);
                 v[u] = t[0]; v[u + 1] = t[1]; v[u + 2] = t[2]; v[u + 3] = t[3];
+            }
+            if (raw_out) {   // a K slice's partial sums: fp32 rows of a workspace plane, finished by the fold kernel
+                store_vec<float, EPC>(raw_out + e, v);
+                continue;
             }
             if (mask) {
                 float mk[EPC];
@@ -555,5 +569,6 @@ bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int*
 bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 int conv_patch_tiles_per_sample(const ConvGemmParams& p, int dtype, int mode = 1);   // mode: ConvGemmParams::tile_stats_mode
 int conv_patch_stats_free(const ConvGemmParams& p, int dtype);
+long conv_patch_ksplit_ws_floats(const ConvGemmParams& p, int dtype);   // workspace of a split-K launch of this layer, 0: none
 
 }  // namespace stmi

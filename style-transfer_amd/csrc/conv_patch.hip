@@ -257,6 +257,13 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     auto div_by = [&](unsigned a, int i) -> unsigned {
         return p.pt_magic[i] ? __umulhi(a, p.pt_magic[i]) : (p.pt_div[i] == 1 ? a : a / p.pt_div[i]);
     };
+    // split K: the grid is pt_ksplit copies of the tile list, copy s owning channel chunks kc0 .. kc0 + nchunks
+    int kslice = 0;
+    if (p.pt_ksplit > 1) {
+        const unsigned per_slice = gridDim.x / (unsigned)p.pt_ksplit;
+        kslice = (int)(tile / per_slice);
+        tile -= (unsigned)kslice * per_slice;
+    }
     unsigned tp_id = div_by(tile, 0);
     const int co0 = (tile - tp_id * p.pt_div[0]) * BLK_CO;
     unsigned q = div_by(tp_id, 1);
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
     const unsigned n_img = div_by(q, 2);
     const int ty0 = (q - n_img * p.pt_div[2]) * PH;
     const int n = (int)n_img;
-    const int nchunks = p.klen / BK;
+    const int kc0 = kslice * p.pt_kchunks;
+    const int nchunks = p.pt_ksplit > 1 ? min(p.pt_kchunks, p.klen / BK - kc0) : p.klen / BK;
 
     STMI_STAMP(0);
     f32x4 acc[TC][TP];
@@ -280,8 +288,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         // one producer and one consumer wave).
         const int pw = wave - 4;
         const int sub = lane >> 3, pos = lane & 7;
-        const T* in = (const T*)p.in;
-        const T* wp = (const T*)p.wp;
+        const T* in = (const T*)p.in + kc0 * BK;
+        const T* wp = (const T*)p.wp + kc0 * BK;
         const T* zero_src = (const T*)(g_patch_zero_page + pos);
         int wrow_off[NI_W];
 #pragma unroll
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
         // this wave's share of the first patch (the producer wave of the same index takes the rest)
         {
             const int sub = lane >> 3, pos = lane & 7;
-            const T* in = (const T*)p.in;
+            const T* in = (const T*)p.in + kc0 * BK;
 #pragma unroll
             for (int i = kProloguePieces; i < kPatchPieces; i++) {
                 const int pr = (wave * kPatchPieces + i) * 8 + sub;
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             const int f = pl >> 4;
             const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (pl & 15);
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
-        }, ts_out);
+        }, ts_out, p.pt_ksplit > 1 ? p.ksplit_ws + (long)kslice * p.ksplit_plane : nullptr);
     } else if (wave < 4) {
         const int wc = wave >> 1, wpx = wave & 1;
         const int g = lane >> 4, r16 = lane & 15;
@@ -1039,7 +1047,10 @@ static int launch_patch(const ConvGemmParams& p, hipStream_t s) {
     }
     // a layer with a single channel chunk never touches the second patch buffer
     const size_t lds_bytes = ONE ? kLds - 4 * kPatchPieces * 8 * 128 : kLds;
-    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW, ONE>), dim3((unsigned)tiles), dim3(512), lds_bytes, s, q);
+    const long blocks = tiles * (q.pt_ksplit > 1 ? q.pt_ksplit : 1);
+    STMI_REQUIRE(blocks < (1L << 31) && !(ONE && q.pt_ksplit > 1), "conv: bad split-K launch");
+    if (q.pt_ksplit > 1) q.pt_wepi = 0;
+    hipLaunchKernelGGL((conv_patch_kernel<T, TC, PW, NSW, ONE>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q);
     STMI_LAUNCH_CHECK("conv_patch_kernel");
     return STMI_OK;
 }
@@ -1171,9 +1182,111 @@ int conv_patch_stats_free(const ConvGemmParams& p, int dtype) {
     return patch_eligible(p, dtype) && !STMI_ENV_SET("STMI_NO_PATCH") && p.row_store_ok && patch_stats_persistent(p, dtype);
 }
 
-bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
-    if (!patch_eligible(p, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
+// Second launch of a split-K convolution: out = epilogue(sum of the slices' planes, in slice order).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_ksplit_fold_kernel(const float* __restrict__ ws, long plane, int ksplit,
+                                                               T* __restrict__ out, T* __restrict__ out_pre,
+                                                               const float* __restrict__ bias, const T* __restrict__ mask,
+                                                               const T* __restrict__ addend, float alpha, int relu,
+                                                               long pieces, int Co) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long idx = blockIdx.x * 256L + threadIdx.x;   // 16-byte piece of the written tensor ([pixel][Co], Co % EPC == 0)
+    if (idx >= pieces) return;
+    const long e = idx * EPC;
+    float v[EPC];
+#pragma unroll
+    for (int u = 0; u < EPC; u++) v[u] = 0.f;
+    for (int sl = 0; sl < ksplit; sl++) {
+        float t[EPC];
+        load_vec<float, EPC>(ws + sl * plane + e, t);
+#pragma unroll
+        for (int u = 0; u < EPC; u++) v[u] += t[u];
+    }
+    const int c = (int)(e % Co);
+#pragma unroll
+    for (int u = 0; u < EPC; u++) v[u] = (v[u] + (bias ? bias[c + u] : 0.f)) * alpha;
+    if (mask) {
+        float mk[EPC];
+        load_vec<T, EPC>(mask + e, mk);
+#pragma unroll
+        for (int u = 0; u < EPC; u++) v[u] = mk[u] > 0.f ? v[u] : 0.f;
+    }
+    if (addend) {
+        float ad[EPC];
+        load_vec<T, EPC>(addend + e, ad);
+#pragma unroll
+        for (int u = 0; u < EPC; u++) v[u] += ad[u];
+    }
+    if (out_pre) store_vec<T, EPC>(out_pre + e, v);
+    if (relu) {
+#pragma unroll
+        for (int u = 0; u < EPC; u++) v[u] = fmaxf(v[u], 0.f);
+    }
+    store_vec<T, EPC>(out + e, v);
+}
+
+// K slices for a layer whose tiles do not fill the chip (the 16 x 16 maps of VGG conv5_x at 256 x 256 pictures:
+// 64 tiles of 144 K steps on 256 CUs); 1 = no split.  A split shortens the K loop every block walks, and pays
+// for it with a second launch and with the planes of fp32 partial sums written and read back; measured on the
+// VGG shapes (scripts/bench_ksplit.py), per call:
+//   saved   = chunks * (1 - 1/ks) * 1.9 us   (bf16, LDS-bound whatever the tile's channel count; fp32, bound by
+//             its matrix rate: 15 us per chunk on 128-channel tiles)
+//   paid    = 4.5 us + 8 bytes * ks * outputs / 3 TB/s
+// Among the powers of two that divide the chunk count, keep two chunks per slice, stay within one block per CU
+// and fit the workspace, the one with the largest net saving is taken, if that is above 1 us.
+static int patch_ksplit(const ConvGemmParams& p, int dtype, int blk_co) {
+    if (!p.ksplit_ws || !p.row_store_ok || p.tile_stats || STMI_ENV_SET("STMI_NO_KSPLIT")) return 1;
+    const int chunks = p.klen / (dtype == STMI_BF16 ? 64 : 32);
+    const long tiles = patch_tiles(p, blk_co);
+    const long plane = (long)p.N * p.Ho * p.Wo * p.Co;
+    const int forced = STMI_ENV_INT("STMI_KSPLIT", 0);   // measurement knob: any divisor of the chunk count
+    if (forced >= 1) return chunks % forced == 0 && plane * forced <= p.ksplit_ws_floats ? forced : 1;
+    const double chunk_us = dtype == STMI_BF16 ? 1.9 : 15.0 * blk_co / 128.0;
+    int best = 1;
+    double best_net = 1.0;
+    for (int ks = 2; tiles * ks <= 256 && chunks / ks >= 2 && chunks % ks == 0 && plane * ks <= p.ksplit_ws_floats; ks *= 2) {
+        const double net = chunks * (1.0 - 1.0 / ks) * chunk_us - (4.5 + 8.0 * ks * (double)plane / 3e6);
+        if (net > best_net) best = ks, best_net = net;
+    }
+    return best;
+}
+
+long conv_patch_ksplit_ws_floats(const ConvGemmParams& p_in, int dtype) {
+    if (!patch_eligible(p_in, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return 0;
+    ConvGemmParams p = p_in;
+    p.ksplit_ws = reinterpret_cast<float*>(16);   // any non-null value: the plan below only compares sizes
+    p.ksplit_ws_floats = 1L << 60;
     const int co = patch_blk_co(p, dtype);
+    if (patch_persistent(p, dtype, co)) return 0;
+    const int ks = patch_ksplit(p, dtype, co);
+    return ks > 1 ? (long)ks * p.N * p.Ho * p.Wo * p.Co : 0;
+}
+
+template <typename T>
+static int launch_ksplit_fold(const ConvGemmParams& p, int ksplit, hipStream_t s) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long plane = (long)p.N * p.Ho * p.Wo * p.Co, pieces = plane / EPC;
+    hipLaunchKernelGGL(conv_ksplit_fold_kernel<T>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, p.ksplit_ws, plane,
+                       ksplit, (T*)p.out, (T*)p.out_pre, p.bias, (const T*)p.mask, (const T*)p.addend, p.alpha, p.relu,
+                       pieces, p.Co);
+    STMI_LAUNCH_CHECK("conv_ksplit_fold_kernel");
+    return STMI_OK;
+}
+
+bool try_launch_conv_patch(const ConvGemmParams& p_in, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
+    if (!patch_eligible(p_in, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
+    ConvGemmParams p = p_in;
+    const int co = patch_blk_co(p, dtype);
+    const int ksplit = patch_persistent(p, dtype, co) || p.klen == (dtype == STMI_BF16 ? 64 : 32) ? 1 : patch_ksplit(p, dtype, co);
+    if (ksplit > 1) {
+        // the slices leave raw sums; everything the epilogue would have applied moves to the fold launch
+        p.pt_ksplit = ksplit;
+        p.pt_kchunks = p.klen / (dtype == STMI_BF16 ? 64 : 32) / ksplit;
+        p.ksplit_plane = (long)p.N * p.Ho * p.Wo * p.Co;
+        p.bias = nullptr; p.mask = nullptr; p.addend = nullptr; p.out_pre = nullptr; p.relu = 0; p.alpha = 1.f;
+    } else {
+        p.pt_ksplit = 1;
+    }
     if (p.tile_stats && p.tile_stats_mode == 1 && patch_stats_two_rows(p, dtype) && !patch_wepi(p, dtype, co)) {
         set_error("conv: the tile statistics of this geometry (two rows per tile) come from the plain convolution only: "
                   "no bias, ReLU, mask, addend or pre-activation copy, fewer than 2^31 output elements");
@@ -1190,15 +1303,17 @@ bool try_launch_conv_patch(const ConvGemmParams& p, int dtype, hipStream_t s, in
         return true;
     }
     if (name)
-        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)",
+        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)%s",
                  dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),
-                 p.klen == (dtype == STMI_BF16 ? 64 : 32) ? "true" : "false");
+                 p.klen == (dtype == STMI_BF16 ? 64 : 32) ? "true" : "false", ksplit > 1 ? " [split K]" : "");
     if (dtype == STMI_BF16)
         *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s)
                         : (co == 64 ? launch_patch_w<bf16_t, 2>(p, s) : launch_patch_w<bf16_t, 1>(p, s));
     else
         *rc = co == 128 ? launch_patch_w<float, 4>(p, s)
                         : (co == 64 ? launch_patch_w<float, 2>(p, s) : launch_patch_w<float, 1>(p, s));
+    if (*rc == STMI_OK && ksplit > 1)
+        *rc = dtype == STMI_BF16 ? launch_ksplit_fold<bf16_t>(p_in, ksplit, s) : launch_ksplit_fold<float>(p_in, ksplit, s);
     return true;
 }
 

@@ -27,7 +27,8 @@ SIGNATURES = {
     'stmi_conv_packed_elems': (_c_long, [_c_int] * 5),
     'stmi_pack_conv_weights': (_c_int, [_vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
-    'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + _CONV + [_c_int, _c_int, _vp]),
+    'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + [_vp, _c_long] + _CONV + [_c_int, _c_int, _vp]),
+    'stmi_conv2d_ksplit_ws_floats': (_c_long, _CONV + [_c_int, _c_int]),
     'stmi_conv2d_tile_stats_tiles': (_c_int, [_c_int] * 9),
     'stmi_conv2d_tile_stats_free': (_c_int, [_c_int] * 9),
     'stmi_conv2d_nhwc_fwd_tile_stats': (_c_int, [_vp] * 6 + _CONV + [_c_int, _c_int, _vp]),
@@ -38,7 +39,7 @@ SIGNATURES = {
     'stmi_conv2d_rgb_nhwc_dgrad': (_c_int, [_vp] * 3 + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_to3_supported': (_c_int, [_c_int] * 3),
     'stmi_conv2d_to3_nhwc_fwd': (_c_int, [_vp] * 4 + [_c_int] * 6 + [_vp]),
-    'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float] + _CONV + [_c_int, _vp]),
+    'stmi_conv2d_nhwc_dgrad': (_c_int, [_vp] * 5 + [_c_float, _vp, _c_long] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_dgrad_in_sums_tiles': (_c_int, [_c_int] * 9),
     'stmi_conv2d_nhwc_dgrad_in_sums': (_c_int, [_vp] * 5 + [_c_float] + [_vp] * 4 + [_c_int, _vp] + _CONV + [_c_int, _vp]),
     'stmi_last_wgrad_kernel': (_c_int, [ctypes.c_char_p, _c_int]),

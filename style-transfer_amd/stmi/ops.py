@@ -111,9 +111,19 @@ def pack_conv_weights_multi(src_flat, dst_flat, table):
 
 
 # ------------------------------------------------------------------- conv
+def conv_ksplit_ws_floats(x_shape, kshape, stride, dtype, dgrad=False):
+    """Floats of workspace with which conv2d_fwd (conv2d_dgrad when `dgrad`; x_shape is then the shape of dx) splits
+    the K loop of this geometry over several blocks per tile; 0: it never does."""
+    kh, kw, ci, co = kshape
+    n, h, w, _ = x_shape
+    return int(_lib.load().stmi_conv2d_ksplit_ws_floats(n, h, w, ci, co, kh, kw, stride, _DT[dtype], int(dgrad)))
+
+
 def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=False, out=None, out_pre=None,
-               tile_stats=None):
+               tile_stats=None, ws=None):
     """kshape = (kh, kw, ci, co) of the HWIO weight that was packed with PACK_FWD.
+    ws: optional fp32 workspace; layers with too few tiles to fill the chip then split their K loop (see
+    conv_ksplit_ws_floats).
     tile_stats: fp32 [n, conv_tile_stats_tiles(...), 4, co] that receives per-tile sums of the output for
     instance_norm_fwd(..., tile_stats=)."""
     kh, kw, ci, co = kshape
@@ -136,7 +146,10 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
                                                        int(relu), _dt(x)),
                    co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
         return (y, pre) if want_pre else y
+    if ws is not None:
+        _chk(ws, 'ws', torch.float32)
     _conv_call('stmi_conv2d_nhwc_fwd', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(pre),
+                                        _ptr(ws), 0 if ws is None else ws.numel(),
                                         n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x)),
                co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
     return (y, pre) if want_pre else y
@@ -249,7 +262,8 @@ def conv2d_rgb_dgrad(dy, w_packed, k, ci, out=None):
     return dx
 
 
-def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None, in_bwd=None):
+def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=None, alpha=1.0, out=None, in_bwd=None,
+                 ws=None):
     """Gradient w.r.t. the conv input of spatial size in_hw; W packed with PACK_DGRAD.
     in_bwd = (x, stats, scale, shift, act, rows): the instance norm whose OUTPUT gradient this call writes;
     rows fp32 [n, conv_dgrad_in_sums_tiles(...), 2, ci] receives the sums instance_norm_bwd(..., rows=) folds."""
@@ -275,8 +289,11 @@ def conv2d_dgrad(dy, w_packed, kshape, stride, in_hw, relu_mask=None, addend=Non
                     bx.data_ptr(), bstats.data_ptr(), bscale.data_ptr(), bshift.data_ptr(), int(bact), rows.data_ptr(),
                     n, h, w, ci, co, kh, kw, stride, _dt(dy)), ci, n * h * w, co, kh * kw, stride)
         return dx
+    if ws is not None:
+        _chk(ws, 'ws', torch.float32)
     _conv_call('stmi_conv2d_nhwc_dgrad', (dy.data_ptr(), w_packed.data_ptr(), dx.data_ptr(), _ptr(relu_mask),
-                                          _ptr(addend), float(alpha), n, h, w, ci, co, kh, kw, stride, _dt(dy)),
+                                          _ptr(addend), float(alpha), _ptr(ws), 0 if ws is None else ws.numel(),
+                                          n, h, w, ci, co, kh, kw, stride, _dt(dy)),
                ci, n * h * w, co, kh * kw, stride)
     return dx
 

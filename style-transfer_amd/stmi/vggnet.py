@@ -121,6 +121,16 @@ class VggReplica:
         # jobs of a pass run in stream order on one stream, so they share one workspace
         need = max(ops.gram_ws_floats(lshape[nm], dt) for nm in self.style_names)
         self.gram_ws = torch.empty(max(need, 4), dtype=torch.float32, device=dev)
+        # raw partial sums of the layers that split their K loop (too few output tiles to fill the chip); the
+        # conv chain of a replica, forward and backward, is one stream order, so one workspace serves all layers
+        need = 0
+        for nm in net.names:
+            if nm.startswith('conv') and not net.convs[nm].rgb:
+                ks = net.convs[nm].kshape
+                hw_ci = (self.shape[nm][1], self.shape[nm][2], ks[2])      # 'same' convolutions of stride 1
+                need = max(need, ops.conv_ksplit_ws_floats((batch,) + hw_ci, ks, 1, dt),
+                           ops.conv_ksplit_ws_floats((nl,) + hw_ci, ks, 1, dt, dgrad=True) if keep else 0)
+        self.ksplit_ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
         self.content = torch.empty(self.shape[self.content_name], dtype=dt, device=dev)
         if keep:
             self.s_packed = [torch.empty(ops.gram_packed_elems(nl, self.shape[nm][3]), dtype=dt, device=dev)
@@ -191,7 +201,7 @@ class VggReplica:
 
                     def conv(src, relu, out, out_pre=None, kshape=kshape):
                         ops.conv2d_fwd(src, L.wp_fwd, kshape, 1, bias=L.bias, relu=relu, want_pre=out_pre is not None,
-                                       out=out, out_pre=out_pre)
+                                       out=out, out_pre=out_pre, ws=self.ksplit_ws)
                 has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
                 tap_pre = (not self.relu_taps) and want_grams and name in STYLE_CONV_TAPS
                 if has_relu:
@@ -375,12 +385,12 @@ class VggReplica:
                         addend = self.gram_grad[self.style_names.index(below)]
                         joined.add(below)
                     ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), relu_mask=lead(self.act[in_name]), addend=addend,
-                                     out=dx)
+                                     out=dx, ws=self.ksplit_ws)
                     g = dx
                     idx -= 1  # the ReLU is folded into the mask
                 else:  # pool output feeds this conv
                     dpool = self._buf(self._gbuf, self._lshape[in_name], (g,))
-                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), out=dpool)
+                    ops.conv2d_dgrad(g, L.wp_bwd, L.kshape, 1, (h, w), out=dpool, ws=self.ksplit_ws)
                     relu_name = names[idx - 2]
                     dx = self._buf(self._gbuf, self._lshape[relu_name], (dpool,))
                     ops.maxpool_bwd(lead(self.act[relu_name]), dpool, out=dx)

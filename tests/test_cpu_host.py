@@ -45,9 +45,9 @@ def test_host_only_queries_need_no_gpu():
 def test_argument_errors_are_reported_not_crashed():
     from stmi import lib
     h = lib.load()
-    assert h.stmi_conv2d_nhwc_fwd(None, None, None, None, None, 1, 8, 8, 8, 8, 3, 3, 1, 0, lib.F32, None) == -1
+    assert h.stmi_conv2d_nhwc_fwd(None, None, None, None, None, None, 0, 1, 8, 8, 8, 8, 3, 3, 1, 0, lib.F32, None) == -1
     assert b'null pointer' in h.stmi_last_error()
-    assert h.stmi_conv2d_nhwc_fwd(1, 1, None, 1, None, 1, 8, 8, 8, 8, 3, 3, 1, 0, 7, None) == -1
+    assert h.stmi_conv2d_nhwc_fwd(1, 1, None, 1, None, None, 0, 1, 8, 8, 8, 8, 3, 3, 1, 0, 7, None) == -1
     assert b'dtype' in h.stmi_last_error()
     assert h.stmi_adam_tf1(1, 1, 1, 1, 10, 1e-3, .9, .999, 1e-8, 1.0, None, 0, None) == -1
     with pytest.raises(lib.StmiError, match='bad arguments'):

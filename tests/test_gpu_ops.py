@@ -100,6 +100,85 @@ def test_conv_dgrad_epilogue(cuda, dtype, chans):
     assert rel_err(got, ref) <= TOL[dtype]
 
 
+KSPLIT_CASES = [
+    # n, h, w, ci, co, forced slices (None: the planner's own choice, which must be a split)
+    (4, 16, 16, 512, 512, None),     # VGG conv5_x of a training batch
+    (1, 16, 16, 512, 512, None),     # ... of one picture
+    (1, 16, 16, 512, 512, 8),        # one chunk per slice (bf16)
+    (2, 9, 7, 256, 256, 2),          # ragged tiles
+    (1, 5, 70, 384, 64, 3),          # a split that is not a power of two
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', KSPLIT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_split_k_convolution_matches_the_oracle_and_the_unsplit_launch(cuda, dtype, case, monkeypatch):
+    """With a workspace, layers of few tiles run their K loop in slices (kernel name says so) and a fold launch
+    applies bias / ReLU / mask / addend / alpha; same answer as the oracle, bit-identical from run to run, and
+    equal to the unsplit launch up to the order of fp32 additions."""
+    from stmi import ops
+    n, h, w, ci, co, forced = case
+    if forced:
+        monkeypatch.setenv('STMI_KSPLIT', str(forced))
+    k = 3
+    ks = (k, k, ci, co)
+    x, wt, bias = rnd((n, h, w, ci), 1), rnd(ks, 2, 1.0 / np.sqrt(9 * ci)), rnd((co,), 3)
+    xq, wq = q(x, dtype).requires_grad_(), q(wt, dtype)
+    y_ref = O.conv2d_same(xq, wq, 1, bias=bias)
+    dy, mask, add = rnd(tuple(y_ref.shape), 4), rnd((n, h, w, ci), 5), rnd((n, h, w, ci), 6)
+    (gx,) = torch.autograd.grad(y_ref, xq, q(dy, dtype))
+    gx_ref = 0.5 * gx * (q(mask, dtype) > 0) + q(add, dtype)
+
+    xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
+    w32 = wt.to(cuda, torch.float32)
+    wf, wd = ops.pack_conv_weights(w32, ops.PACK_FWD, dtype), ops.pack_conv_weights(w32, ops.PACK_DGRAD, dtype)
+    need_f = ops.conv_ksplit_ws_floats((n, h, w, ci), ks, 1, dtype)
+    need_d = ops.conv_ksplit_ws_floats((n, h, w, ci), ks, 1, dtype, dgrad=True)
+    assert need_f > 0 and need_f % (n * h * w * co) == 0 and need_d % (n * h * w * ci) == 0
+    if forced:
+        assert need_f == forced * n * h * w * co
+    ws = torch.full((max(need_f, need_d),), float('nan'), device=cuda)   # every float that is read was written
+    b32 = bias.to(cuda, torch.float32)
+
+    y0, pre0 = ops.conv2d_fwd(xd, wf, ks, 1, bias=b32, relu=True, want_pre=True)
+    assert '[split K]' not in ops.last_conv_kernel()
+    y1, pre1 = ops.conv2d_fwd(xd, wf, ks, 1, bias=b32, relu=True, want_pre=True, ws=ws)
+    assert '[split K]' in ops.last_conv_kernel() and 'conv_patch_kernel' in ops.last_conv_kernel()
+    y2, pre2 = ops.conv2d_fwd(xd, wf, ks, 1, bias=b32, relu=True, want_pre=True, ws=ws)
+    assert torch.equal(y1, y2) and torch.equal(pre1, pre2)
+    assert rel_err(pre1, y_ref) <= TOL[dtype] and rel_err(y1, torch.relu(y_ref)) <= TOL[dtype]
+    assert rel_err(pre1, pre0.double()) <= (2e-6 if dtype == torch.float32 else 8e-3)
+
+    kw = dict(relu_mask=mask.to(cuda, dtype), addend=add.to(cuda, dtype), alpha=0.5)
+    d0 = ops.conv2d_dgrad(dyd, wd, ks, 1, (h, w), **kw)
+    d1 = ops.conv2d_dgrad(dyd, wd, ks, 1, (h, w), ws=ws, **kw)
+    assert ('[split K]' in ops.last_conv_kernel()) == (need_d > 0)
+    d2 = ops.conv2d_dgrad(dyd, wd, ks, 1, (h, w), ws=ws, **kw)
+    assert torch.equal(d1, d2)
+    assert rel_err(d1, gx_ref) <= TOL[dtype]
+    assert rel_err(d1, d0.double()) <= (2e-6 if dtype == torch.float32 else 8e-3)
+    # the addend may be the output itself
+    acc = add.to(cuda, dtype).clone()
+    ops.conv2d_dgrad(dyd, wd, ks, 1, (h, w), relu_mask=kw['relu_mask'], addend=acc, alpha=0.5, out=acc, ws=ws)
+    assert torch.equal(acc, d1)
+
+    # a workspace too small for the planes: the unsplit launch, same bits as without one
+    small = torch.empty(n * h * w * co + 4, device=cuda)
+    y3, _ = ops.conv2d_fwd(xd, wf, ks, 1, bias=b32, relu=True, want_pre=True, ws=small)
+    assert '[split K]' not in ops.last_conv_kernel() and torch.equal(y3, y0)
+
+
+def test_split_k_is_for_layers_that_do_not_fill_the_chip(cuda):
+    from stmi import ops
+    for dtype in DTYPES:
+        assert ops.conv_ksplit_ws_floats((4, 64, 64, 256), (3, 3, 256, 256), 1, dtype) == 0      # 256+ tiles
+        if dtype == torch.bfloat16:   # the planes of a larger batch cost more than the shorter K loop saves
+            assert ops.conv_ksplit_ws_floats((8, 16, 16, 512), (3, 3, 512, 512), 1, dtype) == 0
+        assert ops.conv_ksplit_ws_floats((4, 16, 16, 512), (3, 3, 512, 512), 2, dtype) == 0        # stride 2
+        assert ops.conv_ksplit_ws_floats((4, 16, 16, 512), (1, 1, 512, 512), 1, dtype) == 0
+        assert ops.conv_ksplit_ws_floats((1, 16, 16, 64), (3, 3, 64, 64), 1, dtype) == 0          # one or two chunks
+
+
 RGB_CASES = [(2, 32, 64, 9, 32, False), (1, 37, 45, 9, 32, False), (2, 16, 32, 3, 64, True), (1, 21, 50, 3, 64, True),
              (1, 9, 11, 3, 32, True), (4, 256, 256, 9, 32, False)]
 
