@@ -97,6 +97,14 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
  * the floats with which a geometry splits (0: it never does; dgrad != 0 asks for stmi_conv2d_nhwc_dgrad); a smaller
  * workspace means fewer slices or none, never an error. */
 long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
+
+/* vgg.py:99-103 (conv -> ReLU -> tf.nn.max_pool 2x2 / 2 'SAME'): stmi_conv2d_nhwc_fwd that also leaves the pooled
+ * tensor y_pool [n, (ho+1)/2, (wo+1)/2, co] (= stmi_maxpool2x2_nhwc_fwd of y, bit for bit).  3x3 stride-1 layers
+ * with at least 128 bytes of channels pool the tile they store inside the convolution's launch; every other
+ * geometry runs the two launches. */
+int stmi_conv2d_nhwc_fwd_pool(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pool,
+                              int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                              int relu, int dtype, void* stream);
 int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pre,
                          float* ws, long ws_floats,
                          int n, int h, int w, int ci, int co, int kh, int kw, int stride,

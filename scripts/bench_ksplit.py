@@ -34,23 +34,24 @@ def run(fn, iters=20):
     return e0.elapsed_time(e1) / (5 * iters) * 1e3
 
 
-splits = [0, 1, 2, 4, 8, 16]
-print('%-7s %2s | %8s | ' % ('layer', 'B', 'auto ks') + ' '.join('%8s' % ('ks=%d' % k if k else 'auto') for k in splits) + '   (us per call)')
-for B in [int(b) for b in os.environ.get('B', '1,4,8').split(',')]:
-    for name, h, w, ci, co in LAYERS:
-        x = torch.randn((B, h, w, ci), device=dev).to(dtype)
-        wt = torch.randn((3, 3, ci, co), device=dev) * (2.0 / (9 * ci)) ** 0.5
-        wp = ops.pack_conv_weights(wt, ops.PACK_FWD, dtype)
-        y = torch.empty((B, h, w, co), device=dev, dtype=dtype)
-        bias = torch.zeros(co, device=dev)
-        ws = torch.empty(16 * y.numel(), device=dev)
-        os.environ.pop('STMI_KSPLIT', None)
-        auto = ops.conv_ksplit_ws_floats(x.shape, (3, 3, ci, co), 1, dtype) // y.numel()
-        row = []
-        for k in splits:
-            if k: os.environ['STMI_KSPLIT'] = str(k)
-            else: os.environ.pop('STMI_KSPLIT', None)
-            t = run(lambda: ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, bias=bias, relu=True, out=y, ws=ws))
-            split = '[split K]' in ops.last_conv_kernel()
-            row.append('%7.1f%s' % (t, '*' if split else ' '))
-        print('%-7s %2d | %8d | ' % (name, B, auto) + ' '.join(row))
+if __name__ == '__main__':
+    splits = [0, 1, 2, 4, 8, 16]
+    print('%-7s %2s | %8s | ' % ('layer', 'B', 'auto ks') + ' '.join('%8s' % ('ks=%d' % k if k else 'auto') for k in splits) + '   (us per call)')
+    for B in [int(b) for b in os.environ.get('B', '1,4,8').split(',')]:
+        for name, h, w, ci, co in LAYERS:
+            x = torch.randn((B, h, w, ci), device=dev).to(dtype)
+            wt = torch.randn((3, 3, ci, co), device=dev) * (2.0 / (9 * ci)) ** 0.5
+            wp = ops.pack_conv_weights(wt, ops.PACK_FWD, dtype)
+            y = torch.empty((B, h, w, co), device=dev, dtype=dtype)
+            bias = torch.zeros(co, device=dev)
+            ws = torch.empty(16 * y.numel(), device=dev)
+            os.environ.pop('STMI_KSPLIT', None)
+            auto = ops.conv_ksplit_ws_floats(x.shape, (3, 3, ci, co), 1, dtype) // y.numel()
+            row = []
+            for k in splits:
+                if k: os.environ['STMI_KSPLIT'] = str(k)
+                else: os.environ.pop('STMI_KSPLIT', None)
+                t = run(lambda: ops.conv2d_fwd(x, wp, (3, 3, ci, co), 1, bias=bias, relu=True, out=y, ws=ws))
+                split = '[split K]' in ops.last_conv_kernel()
+                row.append('%7.1f%s' % (t, '*' if split else ' '))
+            print('%-7s %2d | %8d | ' % (name, B, auto) + ' '.join(row))

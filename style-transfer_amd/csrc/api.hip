@@ -43,7 +43,8 @@ int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats,
                         int c, int dtype, hipStream_t s);
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, hipStream_t s,
-                  float* tile_stats = nullptr, int tile_stats_ts = 0, float* ws = nullptr, long ws_floats = 0);
+                  float* tile_stats = nullptr, int tile_stats_ts = 0, float* ws = nullptr, long ws_floats = 0,
+                  void* y_pool = nullptr);
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
                     const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0,
@@ -199,6 +200,14 @@ int stmi_conv2d_nhwc_fwd(const void* x, const void* w_packed_fwd, const float* b
                  "conv2d_nhwc_fwd: the workspace must be 16-byte aligned");
     return conv_fwd_impl(x, w_packed_fwd, bias, y, y_pre, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream),
                          nullptr, 0, ws, ws_floats);
+}
+
+int stmi_conv2d_nhwc_fwd_pool(const void* x, const void* w_packed_fwd, const float* bias, void* y, void* y_pool, int n,
+                              int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_fwd_pool", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    STMI_REQUIRE(x && w_packed_fwd && y && y_pool, "conv2d_nhwc_fwd_pool: null pointer");
+    return conv_fwd_impl(x, w_packed_fwd, bias, y, nullptr, nullptr, n, h, w, ci, co, kh, kw, stride, relu, dtype, S(stream),
+                         nullptr, 0, nullptr, 0, y_pool);
 }
 
 long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad) {

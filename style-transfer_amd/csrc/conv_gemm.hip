@@ -214,6 +214,8 @@ static int launch_typed(const ConvGemmParams& p, hipStream_t s) {
     }
 }
 
+int pool_fwd_impl(const void* x, void* y, int n, int h, int w, int c, int dtype, hipStream_t s);   // pointwise.hip
+
 static thread_local char g_last_conv_kernel[192] = "";
 static const char* kV1Cfg[5] = {"4, 4, 2, 2", "2, 2, 2, 2", "4, 4, 1, 4", "2, 4, 1, 4", "1, 4, 1, 4"};
 
@@ -239,6 +241,16 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
                      ts, p.tile_stats_ts);
         STMI_REQUIRE(!conv_patch_stats_free(p, dtype) || !(p.relu || p.mask || p.addend),
                      "conv: the persistent kernel's tile statistics are those of the plain convolution (no ReLU, mask or addend)");
+    }
+    if (p.pool_out) {
+        // the one-tile patch kernel pools the tile it stores; any other geometry pools y in a launch of its own
+        void* pool = p.pool_out;
+        if (((uintptr_t)pool & 15) == 0 &&
+            try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel)))
+            return rc;
+        p.pool_out = nullptr;
+        rc = launch_conv_gemm(p, dtype, s);
+        return rc ? rc : pool_fwd_impl(p.out, pool, p.N, p.Ho, p.Wo, p.Co, dtype, s);
     }
     if (try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
     if (try_launch_conv_gemm_pc(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
@@ -457,7 +469,7 @@ static void clear_params(ConvGemmParams& p) {
 
 int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, void* y_pre, const void* addend,
                   int n, int h, int w, int ci, int co, int kh, int kw, int stride, int relu, int dtype,
-                  hipStream_t s, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats) {
+                  hipStream_t s, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats, void* y_pool) {
     ConvGemmParams p;
     clear_params(p);
     int rc = setup_fwd(p, n, h, w, ci, co, kh, kw, stride);
@@ -465,6 +477,7 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
     p.in = x; p.wp = wp; p.out = y; p.out_pre = y_pre; p.bias = bias; p.addend = addend; p.relu = relu;
     p.tile_stats = tile_stats; p.tile_stats_ts = tile_stats_ts; p.tile_stats_mode = tile_stats ? 1 : 0;
     p.ksplit_ws = ws_floats > 0 ? ws : nullptr; p.ksplit_ws_floats = ws_floats;
+    p.pool_out = y_pool;
     return launch_conv_gemm(p, dtype, s);
 }
 

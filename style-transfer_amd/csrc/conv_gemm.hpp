@@ -33,6 +33,9 @@ struct ConvGemmParams {
     long ksplit_plane;
     float* ksplit_ws;
     long ksplit_ws_floats;
+    // != nullptr (one-tile patch kernel, row-wise epilogue): the block also leaves the 2 x 2 / stride 2 'SAME' max
+    // pool of the values it stores, [N][(Ho + 1) / 2][(Wo + 1) / 2][Co], taken from its staged rows
+    void* pool_out;
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the
@@ -226,7 +229,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, const
     const int cl_rd = (tid % LPR) * EPC;
     const bool col_ok = co0 + cl_rd < p.Co;
     const bool want_stats = TPG == TP && ts_out.base != nullptr;   // block-uniform
-    const bool restage = want_stats && (mask || addend || p.relu);  // the sums are of the FINISHED values
+    // the sums (and a fused pool) are of the FINISHED values
+    const bool restage = (want_stats || (TPG == TP && p.pool_out != nullptr)) && (mask || addend || p.relu);
     constexpr int CT = BLK_CO / 4;                                  // column threads per staged row (4 channels each)
     constexpr int NRG = CT <= NT ? NT / CT : 1;                     // row groups: column thread = (row group, 4 channels)
     float* part = stage + ROWS * STRIDE;                            // [NRG][2][BLK_CO]

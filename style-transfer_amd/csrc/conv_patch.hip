@@ -503,6 +503,40 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p)
             const int oy = ty0 + f / FPR, ox = tx0 + (f % FPR) * 16 + (pl & 15);
             return oy < H && ox < W ? ((img + oy) * W + ox) * p.Co : -1;
         }, ts_out, p.pt_ksplit > 1 ? p.ksplit_ws + (long)kslice * p.ksplit_plane : nullptr);
+        if (p.pool_out) {
+            // 2 x 2 max pool of the tile from the staged rows (finished values; staged row = local pixel):
+            // tiles start at even coordinates and have even sides, so every window lies in one tile
+            constexpr int STRIDE = BLK_CO + 4, LPR = BLK_CO / EPC, QW = PW / 2, QN = (PH / 2) * QW;
+            const float* stage = reinterpret_cast<const float*>(lds);
+            T* __restrict__ pooled = (T*)p.pool_out;
+            const int Hq = (H + 1) >> 1, Wq = (W + 1) >> 1;
+            __syncthreads();
+            for (int task = tid; task < QN * LPR; task += 512) {
+                const int q = task / LPR, cl = (task - q * LPR) * EPC;
+                const int qy = q / QW, qx = q - qy * QW;
+                const int oy = ty0 + 2 * qy, ox = tx0 + 2 * qx;
+                if (oy >= H || ox >= W || co0 + cl >= p.Co) continue;
+                float m[EPC];
+#pragma unroll
+                for (int u = 0; u < EPC; u++) m[u] = -INFINITY;
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++) {
+#pragma unroll
+                    for (int dx = 0; dx < 2; dx++) {
+                        if (oy + dy >= H || ox + dx >= W) continue;
+                        const int ly = 2 * qy + dy, lx = 2 * qx + dx;
+                        const int pl = (ly * FPR + (lx >> 4)) * 16 + (lx & 15);
+#pragma unroll
+                        for (int u = 0; u < EPC; u += 4) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(stage + pl * STRIDE + cl + u);
+                            m[u] = fmaxf(m[u], t[0]); m[u + 1] = fmaxf(m[u + 1], t[1]);
+                            m[u + 2] = fmaxf(m[u + 2], t[2]); m[u + 3] = fmaxf(m[u + 3], t[3]);
+                        }
+                    }
+                }
+                store_vec<T, EPC>(pooled + (((long)n * Hq + (oy >> 1)) * Wq + (ox >> 1)) * p.Co + co0 + cl, m);
+            }
+        }
     } else if (wave < 4) {
         const int wc = wave >> 1, wpx = wave & 1;
         const int g = lane >> 4, r16 = lane & 15;
@@ -1273,10 +1307,34 @@ static int launch_ksplit_fold(const ConvGemmParams& p, int ksplit, hipStream_t s
     return STMI_OK;
 }
 
+// The one-tile kernel at channel tile `co`; true (the launch was made or refused with *rc set).
+static bool launch_patch_any(const ConvGemmParams& p, int dtype, int co, int ksplit, hipStream_t s, int* rc, char* name,
+                             int name_len, const char* suffix) {
+    (void)ksplit;
+    if (name)
+        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)%s",
+                 dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),
+                 p.klen == (dtype == STMI_BF16 ? 64 : 32) ? "true" : "false", suffix);
+    if (dtype == STMI_BF16)
+        *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s)
+                        : (co == 64 ? launch_patch_w<bf16_t, 2>(p, s) : launch_patch_w<bf16_t, 1>(p, s));
+    else
+        *rc = co == 128 ? launch_patch_w<float, 4>(p, s)
+                        : (co == 64 ? launch_patch_w<float, 2>(p, s) : launch_patch_w<float, 1>(p, s));
+    return true;
+}
+
 bool try_launch_conv_patch(const ConvGemmParams& p_in, int dtype, hipStream_t s, int* rc, char* name, int name_len) {
     if (!patch_eligible(p_in, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
     ConvGemmParams p = p_in;
     const int co = patch_blk_co(p, dtype);
+    if (p.pool_out) {
+        // the pool comes from the staged rows of the one-tile kernel's row-wise epilogue
+        // (launches long enough for the persistent kernel gain more from it than from the saved pool launch:
+        // conv2_2 of eight 256 x 256 pictures 45.9 + 6.9 us in two launches against 56.2 us fused in one-tile blocks)
+        if (!p.row_store_ok || p.tile_stats || patch_persistent(p, dtype, co) || STMI_ENV_SET("STMI_NO_POOL_FUSE")) return false;
+        return launch_patch_any(p, dtype, co, 1, s, rc, name, name_len, " [+pool]");
+    }
     const int ksplit = patch_persistent(p, dtype, co) || p.klen == (dtype == STMI_BF16 ? 64 : 32) ? 1 : patch_ksplit(p, dtype, co);
     if (ksplit > 1) {
         // the slices leave raw sums; everything the epilogue would have applied moves to the fold launch
@@ -1302,16 +1360,7 @@ bool try_launch_conv_patch(const ConvGemmParams& p_in, int dtype, hipStream_t s,
         else *rc = launch_patch_pers_w<float, 2>(p, s);
         return true;
     }
-    if (name)
-        snprintf(name, name_len, "void stmi::conv_patch_kernel<%s, %d, %d, 4, %s>(stmi::ConvGemmParams)%s",
-                 dtype == STMI_BF16 ? "__bf16" : "float", co / 32, patch_width(p),
-                 p.klen == (dtype == STMI_BF16 ? 64 : 32) ? "true" : "false", ksplit > 1 ? " [split K]" : "");
-    if (dtype == STMI_BF16)
-        *rc = co == 128 ? launch_patch_w<bf16_t, 4>(p, s)
-                        : (co == 64 ? launch_patch_w<bf16_t, 2>(p, s) : launch_patch_w<bf16_t, 1>(p, s));
-    else
-        *rc = co == 128 ? launch_patch_w<float, 4>(p, s)
-                        : (co == 64 ? launch_patch_w<float, 2>(p, s) : launch_patch_w<float, 1>(p, s));
+    launch_patch_any(p, dtype, co, ksplit, s, rc, name, name_len, ksplit > 1 ? " [split K]" : "");
     if (*rc == STMI_OK && ksplit > 1)
         *rc = dtype == STMI_BF16 ? launch_ksplit_fold<bf16_t>(p_in, ksplit, s) : launch_ksplit_fold<float>(p_in, ksplit, s);
     return true;

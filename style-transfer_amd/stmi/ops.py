@@ -155,6 +155,26 @@ def conv2d_fwd(x, w_packed, kshape, stride, bias=None, relu=False, want_pre=Fals
     return (y, pre) if want_pre else y
 
 
+def conv2d_fwd_pool(x, w_packed, kshape, stride, bias=None, relu=True, out=None, out_pool=None):
+    """conv2d_fwd that also leaves maxpool_fwd(y) (vgg.py:99-103); 3x3 stride-1 layers of >= 128 bytes of channels
+    pool inside the convolution's launch (last_conv_kernel() then ends in ' [+pool]').  Returns (y, pooled)."""
+    kh, kw, ci, co = kshape
+    n, h, w, c = x.shape
+    assert c == ci, (c, ci)
+    _chk(x, 'x')
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, ci, co, PACK_FWD),))
+    oshape = (n, same_out(h, stride), same_out(w, stride), co)
+    pshape = (n, (oshape[1] + 1) // 2, (oshape[2] + 1) // 2, co)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    yp = torch.empty(pshape, dtype=x.dtype, device=x.device) if out_pool is None else _chk(out_pool, 'out_pool', x.dtype, pshape)
+    if bias is not None:
+        _chk(bias, 'bias', torch.float32, (co,))
+    _conv_call('stmi_conv2d_nhwc_fwd_pool', (x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), yp.data_ptr(),
+                                             n, h, w, ci, co, kh, kw, stride, int(relu), _dt(x)),
+               co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
+    return y, yp
+
+
 def conv_tile_stats_free(x_shape, kshape, stride, dtype):
     """True when the statistics rows of this geometry cost the convolution nothing (the persistent kernel)."""
     n, h, w, ci = x_shape

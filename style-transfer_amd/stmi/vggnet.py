@@ -199,7 +199,10 @@ class VggReplica:
                         cur = ops.pixels_to_rows(cur, k, -((k - 1) // 2), out=self.rows_buf)
                         kshape = (k, 1, 32, kshape[3])
 
-                    def conv(src, relu, out, out_pre=None, kshape=kshape):
+                    def conv(src, relu, out, out_pre=None, kshape=kshape, out_pool=None):
+                        if out_pool is not None:
+                            ops.conv2d_fwd_pool(src, L.wp_fwd, kshape, 1, bias=L.bias, relu=relu, out=out, out_pool=out_pool)
+                            return
                         ops.conv2d_fwd(src, L.wp_fwd, kshape, 1, bias=L.bias, relu=relu, want_pre=out_pre is not None,
                                        out=out, out_pre=out_pre, ws=self.ksplit_ws)
                 has_relu = i + 1 < len(names) and names[i + 1].startswith('relu')
@@ -212,6 +215,17 @@ class VggReplica:
                     else:
                         y = self._buf(self._scratch, shape, (cur,))
                         pre = self._buf(self._scratch, shape, (cur, y)) if tap_pre else None
+                    # conv -> ReLU -> pool: the convolution's launch leaves the pooled tensor as well
+                    pname = names[i + 2] if i + 2 < len(names) and names[i + 2].startswith('pool') else None
+                    if pname is not None and pre is None and not (i == 0 and rgb_first):
+                        yp = self.act[pname] if self.keep else self._buf(self._scratch, self.shape[pname], (cur, y))
+                        conv(cur, True, y, out_pool=yp)
+                        self._flush_side()
+                        self._tap(rname, y)
+                        cur = yp
+                        i += 3
+                        yield
+                        continue
                     conv(cur, True, y, pre)
                     self._flush_side()
                     self._tap(name, pre)

@@ -100,6 +100,41 @@ def test_conv_dgrad_epilogue(cuda, dtype, chans):
     assert rel_err(got, ref) <= TOL[dtype]
 
 
+POOL_CASES = [
+    # n, h, w, ci, co
+    (2, 16, 64, 64, 64),      # one channel chunk (VGG conv1_2 form), 4 x 32 tiles
+    (1, 12, 40, 128, 128),    # 128-channel tiles, ragged right edge
+    (2, 11, 37, 128, 64),     # odd sizes: windows cut by the bottom and right edges
+    (1, 16, 16, 256, 512),    # 8 x 16 tiles
+    (3, 5, 5, 8, 16),         # not a patch-kernel layer: two launches, same answer
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', POOL_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_with_fused_pool_equals_conv_then_pool(cuda, dtype, case):
+    """vgg.py:99-103: conv -> ReLU -> 2x2 max pool.  The pooled tensor a convolution's launch leaves is bit for bit
+    the pool of the tensor it stores, and that tensor is the one the plain launch stores."""
+    from stmi import ops
+    n, h, w, ci, co = case
+    ks = (3, 3, ci, co)
+    x, wt, bias = rnd((n, h, w, ci), 1), rnd(ks, 2, 1.0 / np.sqrt(9 * ci)), rnd((co,), 3)
+    xd = x.to(cuda, dtype)
+    wf = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    b32 = bias.to(cuda, torch.float32)
+    y0 = ops.conv2d_fwd(xd, wf, ks, 1, bias=b32, relu=True)
+    p0 = ops.maxpool_fwd(y0)
+    y1, p1 = ops.conv2d_fwd_pool(xd, wf, ks, 1, bias=b32, relu=True)
+    fused = ci * (2 if dtype == torch.bfloat16 else 4) >= 128
+    assert ('[+pool]' in ops.last_conv_kernel()) == fused, ops.last_conv_kernel()
+    assert torch.equal(y1, y0) and torch.equal(p1, p0)
+    ref = torch.relu(O.conv2d_same(q(x, dtype), q(wt, dtype), 1, bias=bias))
+    assert rel_err(p1, O.max_pool_2x2_same(ref)) <= TOL[dtype]
+    # without the ReLU (finished values = staged values)
+    y2, p2 = ops.conv2d_fwd_pool(xd, wf, ks, 1, bias=b32, relu=False)
+    assert torch.equal(p2, ops.maxpool_fwd(ops.conv2d_fwd(xd, wf, ks, 1, bias=b32)))
+
+
 KSPLIT_CASES = [
     # n, h, w, ci, co, forced slices (None: the planner's own choice, which must be a split)
     (4, 16, 16, 512, 512, None),     # VGG conv5_x of a training batch
