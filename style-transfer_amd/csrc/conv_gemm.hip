@@ -235,13 +235,17 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int dtype, hipStream_t s) {
     ConvGemmParams p = p_in;
     set_row_store(p, dtype);
     if (p.tile_stats) {
-        const int ts = conv_patch_tiles_per_sample(p, dtype, p.tile_stats_mode);
+        const int ts = p.in_stride == 2 ? conv_dn2_tile_stats_tiles(p, dtype) : conv_patch_tiles_per_sample(p, dtype, p.tile_stats_mode);
         STMI_REQUIRE(ts > 0 && ts == p.tile_stats_ts,
                      "conv: tile statistics asked for a layer whose kernel does not produce them (tiles %d, caller's %d)",
                      ts, p.tile_stats_ts);
         STMI_REQUIRE(!conv_patch_stats_free(p, dtype) || !(p.relu || p.mask || p.addend),
                      "conv: the persistent kernel's tile statistics are those of the plain convolution (no ReLU, mask or addend)");
     }
+    if (try_launch_conv_dn2(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+    STMI_REQUIRE(!(p.tile_stats && p.in_stride == 2),
+                 "conv: the tile statistics of a stride-2 layer come from the plain convolution on 16-byte aligned tensors "
+                 "only (no bias, ReLU, mask, addend or pre-activation copy)");
     if (p.pool_out) {
         // the one-tile patch kernel pools the tile it stores; any other geometry pools y in a launch of its own
         void* pool = p.pool_out;
@@ -509,6 +513,7 @@ static int tile_stats_rows(int n, int h, int w, int ci, int co, int kh, int kw, 
     clear_params(p);
     if (setup_fwd(p, n, h, w, ci, co, kh, kw, stride)) return 0;
     p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    if (stride == 2 && mode == 1) return conv_dn2_tile_stats_tiles(p, dtype);
     return conv_patch_tiles_per_sample(p, dtype, mode);
 }
 
@@ -522,6 +527,7 @@ int conv_fwd_tile_stats_free(int n, int h, int w, int ci, int co, int kh, int kw
     clear_params(p);
     if (setup_fwd(p, n, h, w, ci, co, kh, kw, stride)) return 0;
     p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    if (stride == 2) return conv_dn2_tile_stats_tiles(p, dtype) > 0;   // taken from the staged rows, on the matrix cores in bf16
     return conv_patch_stats_free(p, dtype);
 }
 

@@ -417,7 +417,8 @@ __device__ __forceinline__ void conv_epilogue_linear(const ConvGemmParams& p, co
 //   fp32: shifted sums in the lanes that store the rows (WaveStatsLanes).
 // The four waves' partial rows meet in LDS (`part`: 4 x 4 x CO floats) and leave as ONE row per block.
 // ---------------------------------------------------------------------------
-template <int CO>
+// NH: 32-pixel halves of the staged rows (2: 64 pixels, 1: 32)
+template <int CO, int NH = 2>
 __device__ __forceinline__ void wave_stats_mma(const char* stage, int srow, int lane, f32x4 (&acc_s)[CO / 16],
                                                f32x4 (&acc_q)[CO / 16]) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -426,7 +427,7 @@ __device__ __forceinline__ void wave_stats_mma(const char* stage, int srow, int 
 #pragma unroll
     for (int u = 0; u < 8; u++) ones[u] = (__bf16)1.0f;
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < NH; h++)
 #pragma unroll
         for (int k = 0; k < CO / 16; k++) {
             // 16 channels (16 k ..) x 32 pixels (32 h ..): lane (g, q, pp) reads 8 bytes of rows 4 g + q and + 16
@@ -563,9 +564,10 @@ bool try_launch_conv_gemm_pc_multi(ConvGemmParams& p, int dtype, hipStream_t s, 
 int conv_up2_tile_stats_tiles(const ConvGemmParams& p, int dtype);
 bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
-// Stride-2 backward-data / transposed 3x3 convolution with the input patch resident in LDS (conv_up2.hip), for
-// the multi-class form of the launch (p.nclasses parity classes); false when it does not fit.
-bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
+// Stride-2 3x3 forward convolution on even image sides with the input patch resident in LDS (conv_dn2.hip);
+// false when the launch is not one of its layers.  conv_dn2_tile_stats_tiles: statistics rows per sample it leaves.
+int conv_dn2_tile_stats_tiles(const ConvGemmParams& p, int dtype);
+bool try_launch_conv_dn2(const ConvGemmParams& p, int dtype, hipStream_t s, int* rc, char* name, int name_len);
 
 // 3x3 stride-1 kernel with the input patch resident in LDS (conv_patch.hip).  Returns true
 // and launches when the problem fits it; name (optional) receives the kernel's name as a

@@ -454,6 +454,74 @@ def test_conv_transpose_tile_statistics_feed_instance_norm(cuda, dtype, case):
     assert rel_err(y_b, ref) <= TOL[dtype]
 
 
+DN2_CASES = [
+    # n, h, w, ci, co: the stylizer's down-sampling layers (3x3, stride 2) on even image sides
+    (2, 16, 64, 32, 64),       # whole 4 x 32 tiles
+    (1, 10, 70, 64, 128),      # ragged right and bottom tiles (output 5 x 35)
+    (3, 2, 2, 32, 64),         # one output pixel
+    (1, 72, 136, 64, 128),     # more tile rows than the apply blocks fold (18 x 3 tiles)
+    (2, 12, 20, 16, 64),       # fp32: one chunk per pixel pair
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', DN2_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_stride2_patch_kernel_and_its_tile_statistics(cuda, dtype, case):
+    """model_utilities.py:236-237 with stride 2: the LDS-resident pair-patch kernel against the oracle and against
+    the gather-GEMM form; with tile_stats= the output is unchanged, the sums are those of the stored tensor (equal to
+    the separate statistics pass to fp32 summation order) and the normalized result meets the oracle."""
+    from stmi import ops
+    n, h, w, ci, co = case
+    k, s = 3, 2
+    ks = (k, k, ci, co)
+    x = rnd((n, h, w, ci), 1) * 0.5 + 0.8
+    wt = rnd(ks, 2, 1.0 / np.sqrt(k * k * ci))
+    wt[1, 1] += 0.05           # non-zero-mean output
+    scale, shift = rnd((co,), 3) + 1.5, rnd((co,), 4)
+    xd = x.to(cuda, dtype)
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    mine = ci * (2 if dtype == torch.bfloat16 else 4) * 2 % 128 == 0
+    y = ops.conv2d_fwd(xd, wp, ks, s)
+    assert ('conv_dn2_kernel' in ops.last_conv_kernel()) == mine, ops.last_conv_kernel()
+    y_ref = O.conv2d_same(q(x, dtype), q(wt, dtype), s)
+    assert rel_err(y, y_ref) <= TOL[dtype]
+    ts = ops.conv_tile_stats_tiles(xd.shape, ks, s, dtype)
+    if not mine:
+        assert ts == 0
+        return
+    pw = 16 if (dtype == torch.float32 and ci == 64) else 32
+    assert ts == -(-(h // 2) // 4) * -(-(w // 2) // pw)
+    assert ops.conv_tile_stats_free(xd.shape, ks, s, dtype)
+    tiles = torch.full((n, ts, 4, co), float('nan'), dtype=torch.float32, device=cuda)
+    y_t = ops.conv2d_fwd(xd, wp, ks, s, tile_stats=tiles)
+    assert torch.equal(y_t, y), 'the statistics must not change the output'
+    assert bool(torch.isfinite(tiles).all())
+    assert tiles[:, :, 3].sum(dim=1).eq((h // 2) * (w // 2)).all(), 'tile pixel counts add up to the plane'
+    sd, hd = scale.to(cuda, torch.float32), shift.to(cuda, torch.float32)
+    y_a, st_a = ops.instance_norm_fwd(y, sd, hd, ops.ACT_RELU, tile_stats=tiles)
+    y_b, st_b = ops.instance_norm_fwd(y, sd, hd, ops.ACT_RELU)
+    assert rel_err(st_a[..., 0], st_b[..., 0]) <= 1e-5
+    assert rel_err(st_a[..., 1], st_b[..., 1]) <= 1e-4
+    ref = torch.relu(O.instance_norm(y_ref, scale.float().double(), shift.float().double()))
+    assert rel_err(y_a, ref) <= TOL[dtype]
+    assert rel_err(y_b, ref) <= TOL[dtype]
+
+
+def test_stride2_patch_kernel_equals_the_gather_form(cuda, monkeypatch):
+    from stmi import ops
+    for dtype in DTYPES:
+        x, wt = rnd((2, 20, 44, 64), 1), rnd((3, 3, 64, 128), 2, 0.05)
+        xd = x.to(cuda, dtype)
+        wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+        y = ops.conv2d_fwd(xd, wp, (3, 3, 64, 128), 2)
+        assert 'conv_dn2_kernel' in ops.last_conv_kernel()
+        monkeypatch.setenv('STMI_NO_DN2', '1')
+        y_g = ops.conv2d_fwd(xd, wp, (3, 3, 64, 128), 2)
+        assert 'conv_dn2_kernel' not in ops.last_conv_kernel()
+        monkeypatch.delenv('STMI_NO_DN2')
+        assert rel_err(y, y_g.double()) <= (2e-6 if dtype == torch.float32 else 8e-3)
+
+
 PERS_CASES = [(3, 130, 250, 128, 64), (3, 126, 260, 128, 128), (2, 254, 250, 64, 64)]   # three block rounds and more
 
 
