@@ -1117,4 +1117,6 @@ def test_pack_multi_matches_single_packs_and_kernel_name(cuda):
     ops.conv2d_fwd(x, wp, (3, 3, 64, 64), 1)
     assert 'conv_patch_kernel<__bf16' in ops.last_conv_kernel()
     ops.conv2d_fwd(x, wp, (3, 3, 64, 64), 2)
+    assert 'conv_dn2_kernel<__bf16' in ops.last_conv_kernel()
+    ops.conv2d_fwd(x[:, :7], wp, (3, 3, 64, 64), 2)     # odd side: pads above as well, the gather form
     assert 'conv_gemm_pc_kernel<__bf16' in ops.last_conv_kernel()
