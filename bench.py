@@ -134,6 +134,9 @@ def roofline_of(eager_pass, dtype_name, workload):
     torch.cuda.synchronize()
     log, ops.PROFILE = ops.PROFILE, None
     hbm_log, ops.PROFILE_HBM = ops.PROFILE_HBM, None
+    # one group per kernel INSTANTIATION, as a profiler's per-kernel table has it: the library's notes behind a name
+    # (" [+pool]", " [split K]": options of the same device function) do not make a kernel of their own
+    log = [(name.split(' [')[0], flops, relaunch) for name, flops, relaunch in log]
     groups = {}
     for name, flops, relaunch in log:
         groups.setdefault(name, []).append((flops, relaunch))
