@@ -36,6 +36,13 @@ struct ConvGemmParams {
     // != nullptr (one-tile patch kernel, row-wise epilogue): the block also leaves the 2 x 2 / stride 2 'SAME' max
     // pool of the values it stores, [N][(Ho + 1) / 2][(Wo + 1) / 2][Co], taken from its staged rows
     void* pool_out;
+    // != nullptr (persistent patch kernel, bf16, wave-private epilogue, at most 128 input channels): the input is the
+    // raw input of an instance norm + ReLU that this convolution absorbs.  With a = scale * rstd > 0, b = shift -
+    // mean * a, t = -b / a:  relu(a x + b) = a * max(x, t) + b, so the launch reads max(x, clamp_t[n][ci]) (one packed
+    // max per fragment register), takes t for taps outside the image (a t + b = 0: the zero padding of the
+    // normalised tensor) and multiplies with per-sample weights W * a (w_batch_stride apart).  What is left out, the
+    // per-(sample, output channel) constant sum(W b), is removed by the instance norm that follows the convolution.
+    const void* clamp_t;
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the

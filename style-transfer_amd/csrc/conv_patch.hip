@@ -222,6 +222,16 @@ __device__ __forceinline__ void patch_wave_epilogue(const ConvGemmParams& p, con
 // ONE: the layer has a single channel chunk (Cin * sizeof(T) == 128): every instruction runs once,
 // i.e. misses the instruction cache once, so that instantiation keeps its code small (rolled tap
 // loop in the MFMA waves, no next-patch logic in the DMA waves).
+// packed maximum of eight 16-bit floats by their bit patterns (see conv_patch_pers_kernel, CLAMP)
+__device__ __forceinline__ void pk_max_bits(u32x4& v, const u32x4& t) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        unsigned r;
+        asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(v[u]), "v"(t[u]));
+        v[u] = r;
+    }
+}
+
 template <typename T, int TC, int PW, int NSW, bool ONE>
 __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvGemmParams p) {
     constexpr int EPC = 16 / sizeof(T);
@@ -595,8 +605,10 @@ constexpr int in_flight_ok_pp(int nsw, int ni_w, int pp, bool last, int t) {
 // statistics from the same rows on the matrix cores (wave_stats_mma; TWO statistics rows per tile, one per pixel
 // half) and starts the next tile.  The DMA waves then have no part in a tile change at all: the four epilogue
 // barriers, the fp32 staging groups and the DMA waves' statistics arithmetic are gone.
-template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false>
+// CLAMP (with WEPI): ConvGemmParams::clamp_t -- the launch absorbs the instance norm + ReLU in front of it.
+template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false, bool CLAMP = false>
 __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmParams p) {
+    static_assert(!CLAMP || (WEPI && sizeof(T) == 2), "the clamp rides on the bf16 wave-private form");
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;
     constexpr int TP = 4;
@@ -656,10 +668,10 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
             const int row = (pw * NI_W + j) * 8 + sub;
             wrow_off[j] = row * p.kpad + (pos ^ ((row >> 1) & 7)) * EPC;
         }
-        int co0 = 0;
+        int co0 = 0, wn = 0;   // channel tile and sample of the weights being staged
         auto stage_weights = [&](int tap_i, int chunk, int slot) {
             const Tap tap = p.taps[tap_i];
-            const T* wsrc = wp + ((long)tap.widx * p.co_pad + co0) * p.kpad + chunk * BK;
+            const T* wsrc = wp + (CLAMP ? (long)wn * p.w_batch_stride : 0L) + ((long)tap.widx * p.co_pad + co0) * p.kpad + chunk * BK;
             const unsigned dst = lds_base + slot * W_SLOT + pw * (NI_W * 1024);
 #pragma unroll
             for (int j = 0; j < NI_W; j++) glds16(wsrc + wrow_off[j], dst + j * 1024);
@@ -690,23 +702,27 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         };
         int poff[PP], poff_next[PP];
         unsigned gc = 0;   // chunks staged so far: selects the patch buffer
-        auto stage_patch_piece = [&](int i, const int (&off)[PP], int chunk, unsigned buf) {
+        // rows outside the image: zeros, or (CLAMP) the sample's clamp values, which the absorbed norm maps to zero
+        const T* t_rows = CLAMP ? (const T*)p.clamp_t + (pos ^ (sub & 7)) * EPC : nullptr;
+        auto stage_patch_piece = [&](int i, const int (&off)[PP], int chunk, unsigned buf, int n_off) {
             const unsigned dst = patch_base + (buf & 1) * P_BUF + (pw * PP + i) * 1024;
-            glds16(off[i] >= 0 ? in + (off[i] + chunk * BK) : zero_src, dst);
+            const T* outside = CLAMP ? t_rows + ((long)n_off * C + chunk * BK) : zero_src;
+            glds16(off[i] >= 0 ? in + (off[i] + chunk * BK) : outside, dst);
         };
         TilePos cur = tile_pos(0);
         co0 = cur.co0;
+        wn = cur.n;
         patch_offsets(cur, poff);
         stage_weights(0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < PP; i++) stage_patch_piece(i, poff, 0, 0);
+        for (int i = 0; i < PP; i++) stage_patch_piece(i, poff, 0, 0, cur.n);
 #pragma unroll
         for (int s = 1; s < NSW - 1; s++) stage_weights(s, 0, s);
 
         int slot = 0;
         // chunk c of the current tile; `next_off` / `next_chunk`: where the chunk after it lives (the next
         // chunk of this tile, or chunk 0 of the next tile); co0_next: the weights' channel tile for that chunk
-        auto chunk_body = [&](auto last_tag, int c, const int (&next_off)[PP], int next_chunk, int co0_next) {
+        auto chunk_body = [&](auto last_tag, int c, const int (&next_off)[PP], int next_chunk, int co0_next, int n_next) {
             constexpr bool LAST = decltype(last_tag)::value;
             static_for<0, 9>([&](auto t_tag) {
                 constexpr int t = decltype(t_tag)::value;
@@ -717,15 +733,17 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
                 if (cn == 0) {
                     stage_weights(tn, c, slot == 0 ? NSW - 1 : slot - 1);
                 } else if (!LAST) {
-                    const int keep = co0;
+                    const int keep = co0, keep_n = wn;
                     co0 = co0_next;
+                    wn = n_next;
                     stage_weights(tn, next_chunk, slot == 0 ? NSW - 1 : slot - 1);
                     co0 = keep;
+                    wn = keep_n;
                 }
                 if (!LAST) {
 #pragma unroll
                     for (int q = 0; q < pieces_at_pp(NSW, PP, t); q++)
-                        stage_patch_piece(pieces_before_pp(NSW, PP, t) + q, next_off, next_chunk, gc + 1);
+                        stage_patch_piece(pieces_before_pp(NSW, PP, t) + q, next_off, next_chunk, gc + 1, n_next);
                 }
                 slot = slot + 1 == NSW ? 0 : slot + 1;
             });
@@ -824,17 +842,18 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
                 nxt = tile_pos(it + 1);
                 patch_offsets(nxt, poff_next);
             }
-            for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c, poff, c + 1, co0);
+            for (int c = 0; c + 1 < nchunks; c++) chunk_body(std::false_type{}, c, poff, c + 1, co0, cur.n);
             if (has_next) {
-                chunk_body(std::false_type{}, nchunks - 1, poff_next, 0, nxt.co0);
+                chunk_body(std::false_type{}, nchunks - 1, poff_next, 0, nxt.co0, nxt.n);
                 // the MFMA waves stage and store tile `it`: their barriers need every wave of the block
                 epilogue_barriers(cur);
 #pragma unroll
                 for (int i = 0; i < PP; i++) poff[i] = poff_next[i];
                 cur = nxt;
                 co0 = cur.co0;
+                wn = cur.n;
             } else {
-                chunk_body(std::true_type{}, nchunks - 1, poff, 0, co0);
+                chunk_body(std::true_type{}, nchunks - 1, poff, 0, co0, cur.n);
                 epilogue_barriers(cur);
             }
         }
@@ -851,14 +870,21 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         const unsigned a_off = lds_base + wc * TC * 2048 + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
         f32x4 acc[TC][TP];
         u32x4 fa[2][TC], fb[2][TP];
+        u32x4 tv[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};   // CLAMP: see below
         auto mma_and_read = [&](auto use_tag, unsigned wbase, const unsigned (&baddr)[TP], bool do_read) {
             constexpr int USE = decltype(use_tag)::value, LOAD = 1 - USE;
             const unsigned flip = LOAD ? 64u : 0u;
+            // CLAMP: a pixel fragment is clamped just before its first product, behind the previous fragment's
+            // MFMA, so that all but the first four packed maxima of a half run under matrix work
+            if constexpr (CLAMP) pk_max_bits(fb[USE][0], tv[USE]);
 #pragma unroll
             for (int tc = 0; tc < TC; tc++) {
 #pragma unroll
                 for (int tp = 0; tp < TP; tp++) {
                     Mma<T>::mma(__builtin_bit_cast(frag, fa[USE][tc]), __builtin_bit_cast(frag, fb[USE][tp]), acc[tc][tp]);
+                    if constexpr (CLAMP) {
+                        if (tc == 0 && tp + 1 < TP) pk_max_bits(fb[USE][tp + 1], tv[USE]);
+                    }
                     if (do_read) {
                         constexpr int RPG = TC * TP >= 16 ? 1 : 2;
 #pragma unroll
@@ -889,6 +915,13 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         constexpr int S_WAVE = 64 * SROW;
         char* const stage_w = reinterpret_cast<char*>(stage) + wave * S_WAVE;
         const unsigned stage_w_addr = lds_base + NSW * W_SLOT + 2 * P_BUF + wave * S_WAVE;
+        // CLAMP: this wave's copy of the current sample's clamp values ([C] of T behind the staging rows), and the
+        // eight values of each K half of the current chunk that go with this lane's fragment registers.  bf16 bit
+        // patterns order like fp16 ones (sign, then magnitude) as long as none reads as an fp16 NaN (|x| >= 2^121),
+        // so the maximum of two packed pairs is ONE v_pk_max_f16.
+        const unsigned tab_addr = lds_base + NSW * W_SLOT + 2 * P_BUF + 4 * S_WAVE + wave * 256;
+        int n_tab = -1;
+        u32x4 tv1_chunk = (u32x4){0u, 0u, 0u, 0u};   // the current chunk's values for K half 1 (tv[1] lags one product)
         auto tap_step = [&](int t, unsigned pbuf) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -901,7 +934,10 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
                 baddr[tp] = pbuf + pr * 128 + ((g ^ (pr & 7)) << 4);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);
+            mma_and_read(std::integral_constant<int, 1>{}, wbase, baddr, true);   // (second half of the PREVIOUS step)
+            if constexpr (CLAMP) {
+                if (t == 0) tv[1] = tv1_chunk;   // ... which at a chunk's first tap still belonged to the chunk before
+            }
             landed(std::integral_constant<int, 0>{});
             mma_and_read(std::integral_constant<int, 0>{}, wbase, baddr, true);
             landed(std::integral_constant<int, 1>{});
@@ -917,8 +953,26 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
             for (int tc = 0; tc < TC; tc++) fa[1][tc] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
             for (int tp = 0; tp < TP; tp++) fb[1][tp] = (u32x4){0u, 0u, 0u, 0u};
+            if constexpr (CLAMP) {
+                if (tp0.n != n_tab) {   // a block's run of tiles changes sample a few times per launch
+                    n_tab = tp0.n;
+                    if (lane * EPC < C) {
+                        const uint4 tvals = *reinterpret_cast<const uint4*>((const T*)p.clamp_t + (long)n_tab * C + lane * EPC);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds) + (tab_addr - lds_base) + lane * 16) = tvals;
+                    }
+                    lds_wait();
+                    asm volatile("" ::: "memory");
+                }
+            }
             for (int c = 0; c < nchunks; c++, gc++) {
                 const unsigned pbuf = patch_base + (gc & 1) * P_BUF;
+                if constexpr (CLAMP) {
+                    tv[0] = lds_read16(tab_addr + (c * BK + 8 * g) * 2, 0);
+                    tv1_chunk = lds_read16(tab_addr + (c * BK + 32 + 8 * g) * 2, 0);
+                    lds_wait();
+                    lds_landed(tv[0]);
+                    lds_landed(tv1_chunk);
+                }
                 static_for<0, 9>([&](auto t_tag) { tap_step(decltype(t_tag)::value, pbuf); });
             }
             mma_and_read(std::integral_constant<int, 1>{}, 0u, baddr, false);
@@ -1015,7 +1069,7 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
 static bool patch_eligible(const ConvGemmParams& p, int dtype) {
     const int bk = dtype == STMI_BF16 ? 64 : 32;
     if (p.ntaps != 9 || p.cdiv != 0 || p.klen <= 0 || p.klen % bk != 0 || p.klen != p.Ci) return false;
-    if (p.w_batch_stride != 0 || p.in_stride != 1 || p.oys != 1 || p.oxs != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
+    if ((p.w_batch_stride != 0 && !p.clamp_t) || p.in_stride != 1 || p.oys != 1 || p.oxs != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
     if (p.Hs != p.Hi || p.Ws != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi) return false;
     if (p.co_pad % 32 != 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31)) return false;
@@ -1152,16 +1206,17 @@ static bool patch_persistent(const ConvGemmParams& p, int dtype, int blk_co) {
     return patch_persistent_shape(p, dtype, blk_co, patch_tiles(p, blk_co));
 }
 
-template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false>
+template <typename T, int TC, int PW, int NSW, bool STATS, bool WEPI = false, bool CLAMP = false>
 static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     constexpr int PH = 128 / PW;
     constexpr size_t kPatch = (size_t)4 * (((PH + 2) * (PW + 2) + 31) / 32) * 8 * 128;
     // WEPI: four waves' rows of 16 TC channels of T (+ 16 bytes)
     constexpr size_t kStage = WEPI ? (size_t)4 * 64 * (16 * TC * sizeof(T) + 16)
                                     : (size_t)16 * (TC >= 4 ? 2 : 4) * 2 * (32 * TC + 4) * 4;
-    constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * kPatch + kStage;
+    // CLAMP: a 256-byte table of clamp values per MFMA wave behind the staging rows
+    constexpr size_t kLds = (size_t)NSW * 32 * TC * 128 + 2 * kPatch + kStage + (CLAMP ? 4 * 256 : 0);
     static_assert(kLds <= 160 * 1024, "operand buffers + staging rows exceed the CU's LDS");
-    STMI_DYN_LDS((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>), (int)kLds, "hipFuncSetAttribute(conv_patch_pers_kernel)");
+    STMI_DYN_LDS((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI, CLAMP>), (int)kLds, "hipFuncSetAttribute(conv_patch_pers_kernel)");
     const long tiles = patch_tiles(p, 32 * TC);
     STMI_REQUIRE(tiles > 0 && tiles < (1L << 31), "conv: tile count out of range");
     ConvGemmParams q = p;
@@ -1174,7 +1229,7 @@ static int launch_patch_pers(const ConvGemmParams& p, hipStream_t s) {
     q.pt_npers = (unsigned)tiles;
     unsigned grid = (unsigned)(device_cus() / 8 * 8);   // a multiple of the eight XCDs
     if ((long)grid > tiles) grid = (unsigned)((tiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI>), dim3(grid), dim3(512), kLds, s, q);
+    hipLaunchKernelGGL((conv_patch_pers_kernel<T, TC, PW, NSW, STATS, WEPI, CLAMP>), dim3(grid), dim3(512), kLds, s, q);
     STMI_LAUNCH_CHECK("conv_patch_pers_kernel");
     return STMI_OK;
 }
@@ -1328,6 +1383,19 @@ bool try_launch_conv_patch(const ConvGemmParams& p_in, int dtype, hipStream_t s,
     if (!patch_eligible(p_in, dtype) || STMI_ENV_SET("STMI_NO_PATCH")) return false;
     ConvGemmParams p = p_in;
     const int co = patch_blk_co(p, dtype);
+    if (p.clamp_t) {
+        // the absorbed-norm form exists as the persistent bf16 kernel with the wave-private epilogue and statistics
+        if (dtype != STMI_BF16 || co != 128 || !patch_wepi(p, dtype, co) || !p.tile_stats || p.tile_stats_mode != 1 ||
+            !patch_stats_two_rows(p, dtype) || p.Ci > 128 || p.w_batch_stride <= 0 || ((uintptr_t)p.clamp_t & 15) != 0 ||
+            p.pool_out || p.ksplit_ws)
+            return false;
+        if (name)
+            snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<__bf16, 4, %d, 4, true, true, true>(stmi::ConvGemmParams)",
+                     patch_width(p));
+        *rc = patch_width(p) == 32 ? launch_patch_pers<bf16_t, 4, 32, 4, true, true, true>(p, s)
+                                   : launch_patch_pers<bf16_t, 4, 16, 4, true, true, true>(p, s);
+        return true;
+    }
     if (p.pool_out) {
         // the pool comes from the staged rows of the one-tile kernel's row-wise epilogue
         // (launches long enough for the persistent kernel gain more from it than from the saved pool launch:

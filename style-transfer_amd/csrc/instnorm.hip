@@ -890,6 +890,53 @@ int in_apply_tiles_impl(const void* x, const float* tiles, int ts, float* stats,
                : apply_typed<float>(x, stats, 2, tiles, ts, eps, scale, shift, residual, y, y_f32, act, n, h, w, c, s);
 }
 
+// statistics [n][c][2] = (mean, rstd) from a convolution's tile sums alone (any number of rows per sample)
+int in_stats_from_tiles_impl(const float* tiles, int ts, float* stats, float eps, int n, int c, hipStream_t s) {
+    if (c % 8 == 0)
+        hipLaunchKernelGGL(in_stats_from_tiles_kernel<8>, dim3(n, c / 8), dim3(256), 0, s, tiles, stats, eps, c, ts);
+    else
+        hipLaunchKernelGGL(in_stats_from_tiles_any_kernel, dim3(n, (c + 7) / 8), dim3(256), 0, s, tiles, stats, eps, c, ts);
+    STMI_LAUNCH_CHECK("in_stats_from_tiles_kernel");
+    return STMI_OK;
+}
+
+// What a convolution that absorbs the instance norm + ReLU in front of it needs (ConvGemmParams::clamp_t): per
+// sample the clamp values t = mean - shift / a (a = scale * rstd; relu(a x + b) = a max(x, t) + b) and a copy of the
+// packed weights [rows][kpad] (K = input channel, contiguous) scaled by a along K.  scale must be positive.
+template <typename T>
+__global__ __launch_bounds__(256) void in_absorb_prep_kernel(const float* __restrict__ stats, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const T* __restrict__ wp,
+                                                             T* __restrict__ clamp_t, T* __restrict__ wps, int C, int kpad,
+                                                             long welems) {
+    const int n = blockIdx.y;
+    const float* st = stats + (long)n * C * 2;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < welems; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % kpad);
+        const float a = k < C ? scale[k] * st[2 * k + 1] : 0.f;
+        wps[(long)n * welems + e] = from_f32<T>(to_f32<T>(wp[e]) * a);
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float a = scale[c] * st[2 * c + 1];
+            const float t = st[2 * c] - shift[c] / a;
+            clamp_t[(long)n * C + c] = from_f32<T>(fminf(fmaxf(t, -1e30f), 1e30f));   // far below the fp16-NaN patterns
+        }
+    }
+}
+
+int in_absorb_prep_impl(const float* stats, const float* scale, const float* shift, const void* wp, void* clamp_t,
+                        void* wps, int n, int c, int kpad, long welems, int dtype, hipStream_t s) {
+    const int bx = (int)((welems + 1023) / 1024 > 256 ? 256 : (welems + 1023) / 1024);
+    if (dtype == STMI_BF16)
+        hipLaunchKernelGGL(in_absorb_prep_kernel<bf16_t>, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, s, stats, scale, shift,
+                           (const bf16_t*)wp, (bf16_t*)clamp_t, (bf16_t*)wps, c, kpad, welems);
+    else
+        hipLaunchKernelGGL(in_absorb_prep_kernel<float>, dim3(bx > 0 ? bx : 1, n), dim3(256), 0, s, stats, scale, shift,
+                           (const float*)wp, (float*)clamp_t, (float*)wps, c, kpad, welems);
+    STMI_LAUNCH_CHECK("in_absorb_prep_kernel");
+    return STMI_OK;
+}
+
 // whole forward: statistics pass, then apply (which also leaves the statistics in `stats`)
 int in_fwd_impl(const void* x, float* ws, float* stats, float eps, const float* scale, const float* shift,
                 const void* residual, void* y, float* y_f32, int act, int n, int h, int w, int c, int dtype,

@@ -217,6 +217,8 @@ class StylizerNet:
             self._readers = {}  # data_ptr of a gradient buffer -> (issue number, event) of its last side-stream reader
             self._reader_seq = 0
         self.repack()
+        self._absorb_ws = None
+        self._plan_absorb()
 
     # ------------------------------------------------------------ parameters
     def load_params(self, params):
@@ -225,9 +227,31 @@ class StylizerNet:
             t = torch.as_tensor(np.asarray(p), dtype=torch.float32)
             assert tuple(t.shape) == tuple(v.shape), (tuple(t.shape), tuple(v.shape))
             v.copy_(t)
+        if hasattr(self, '_absorb_ws'):
+            self._plan_absorb()
 
     def export_params(self):
         return [v.detach().cpu().numpy().copy() for v in self.views]
+
+    def _plan_absorb(self):
+        """Inference: where the second convolution of a residual block can absorb the norm + ReLU in front of it
+        (ops.conv2d_fwd_absorb_norm: bf16, 1080p-sized planes, every scale of that norm positive), the apply pass
+        of the block's first norm is not run at all.  Decided from the parameters: call again after changing them."""
+        for b in self.blocks:
+            b.absorb_ws = None
+        if self.training or not tuning.ABSORB_NORM or not tuning.TILE_STATS:
+            return
+        for i, b in enumerate(self.blocks[:-1]):
+            nb = self.blocks[i + 1]
+            if b.role != 'a' or nb.role != 'b' or b.tile_stats is None or nb.tile_stats is None:
+                continue
+            if b.act != ops.ACT_RELU or nb.kind != 'conv' or nb.rows is not None or nb.k != 3 or nb.s != 1:
+                continue
+            need = ops.conv_absorb_norm_ws_bytes((self.n, b.out_h, b.out_w, b.co), nb.co, self.dtype)
+            if need and bool((b.scale > 0).all()):
+                if self._absorb_ws is None or self._absorb_ws.numel() < need:
+                    self._absorb_ws = torch.empty(need, dtype=torch.uint8, device=b.scale.device)
+                b.absorb_ws = self._absorb_ws      # the blocks run in stream order: one workspace serves them all
 
     def repack(self):
         """Refreshes the K-contiguous weight copies after the fp32 masters changed."""
@@ -271,6 +295,7 @@ class StylizerNet:
             self._rows0_ready = True
         cur = self.x_in
         skip = None
+        absorbed = None      # the block whose norm the next convolution absorbs
         last = len(self.blocks) - 1
         for i, b in enumerate(self.blocks):
             if self.training:
@@ -294,10 +319,19 @@ class StylizerNet:
             elif b.rows == 'out':
                 ops.conv2d_fwd(cur, b.wp_fwd, (b.k, 1, b.ci, 32), 1, out=b.rows_buf)
                 ops.rows_to_pixels_sum(b.rows_buf, b.co, b.k, -b.pad_left, out=conv_out)
+            elif absorbed is not None:
+                # cur is the raw output of the block's first convolution: its norm + ReLU happen on the way in
+                ops.conv2d_fwd_absorb_norm(cur, absorbed.tile_stats, absorbed.scale, absorbed.shift, b.wp_fwd, b.co,
+                                           b.tile_stats, absorbed.absorb_ws, in_stats=absorbed.stats, out=conv_out)
+                absorbed = None
             else:
                 ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             if b.role == 'a':
                 skip = cur
+                if b.absorb_ws is not None:
+                    absorbed = b
+                    cur = conv_out
+                    continue
             if i == last and out_u8 is not None:
                 ops.instance_norm_stats(conv_out, ws=self.ws, stats=b.stats)
                 ops.instance_norm_apply_u8(conv_out, b.stats, b.scale, b.shift, b.act, out=out_u8)

@@ -15,6 +15,8 @@ compare the families with each other.)
   STMI_TILE_STATS    0: convolutions leave no per-tile sums, every instance norm runs its own statistics pass
   STMI_TILE_STATS_MAX  longest tile row per sample the norm's apply blocks fold themselves   (default: 32)
   STMI_IN_SUMS       0: data-gradient kernels leave no sums for the norm below them
+  STMI_ABSORB_NORM   0: at inference the second convolution of a residual block reads the normalised tensor an
+                     apply pass wrote, instead of absorbing that norm + ReLU itself
   STMI_FUSED_VGG     0: a training step runs the content pictures through a VGG pass of their own (beside the
                      stylizer forward) instead of in ONE pass of 2 x batch samples with the stylized pictures
 """
@@ -32,3 +34,4 @@ TILE_STATS = _flag('STMI_TILE_STATS')
 TILE_STATS_MAX = int(os.environ.get('STMI_TILE_STATS_MAX', '32'))
 IN_SUMS = _flag('STMI_IN_SUMS')
 FUSED_VGG = _flag('STMI_FUSED_VGG')
+ABSORB_NORM = _flag('STMI_ABSORB_NORM')

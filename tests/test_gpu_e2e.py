@@ -437,6 +437,37 @@ def test_inference_1080p_batch16_bf16(cuda):
     assert psnr(batch_out[1:2], ref) >= 40.0
 
 
+def test_absorbed_residual_norms_equal_the_apply_passes(cuda, monkeypatch):
+    """At inference sizes the second convolution of a residual block absorbs the norm + ReLU in front of it
+    (full_graph_stylizer_network.py:52-57 without the normalised tensor in between).  Same picture as the route
+    with the apply passes, within bf16; a non-positive scale in such a norm switches the block back."""
+    from stmi import tuning
+    from stmi.stylizer import StylizerNet
+    params = O.init_stylizer_params(seed=3)
+    g = torch.Generator(device='cpu').manual_seed(11)
+    frames = torch.rand((2, 1024, 1536, 3), generator=g, dtype=torch.float32).to(cuda)
+    net = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)
+    absorbing = [i for i, b in enumerate(net.blocks) if b.absorb_ws is not None]
+    assert len(absorbing) == 5 and all(net.blocks[i].role == 'a' for i in absorbing)
+    out = net.forward(frames).clone()
+    monkeypatch.setattr(tuning, 'ABSORB_NORM', False)
+    plain = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)
+    assert all(b.absorb_ws is None for b in plain.blocks)
+    ref = plain.forward(frames).clone()
+    assert psnr(out.cpu(), ref.cpu()) >= 45.0
+    monkeypatch.setattr(tuning, 'ABSORB_NORM', True)
+    flipped = [np.array(p, copy=True) for p in params]
+    scale_index = 3 * absorbing[0] + 2                 # W, shift, scale per block, in creation order
+    assert flipped[scale_index].shape == (128,)
+    flipped[scale_index][5] = -0.5
+    net.load_params(flipped)
+    net.repack()
+    assert net.blocks[absorbing[0]].absorb_ws is None and net.blocks[absorbing[1]].absorb_ws is not None
+    plain.load_params(flipped)
+    plain.repack()
+    assert psnr(net.forward(frames).cpu(), plain.forward(frames).cpu()) >= 45.0
+
+
 def test_sharded_frames_against_the_oracle(cuda):
     """stylize_frames_sharded (frames split over ranks, no collective; pinned double-buffered staging) against the
     ORACLE, for a frame count that leaves a ragged last chunk: float32 frames in fp32 mode to 1e-3; 8-bit frames

@@ -135,6 +135,61 @@ def test_conv_with_fused_pool_equals_conv_then_pool(cuda, dtype, case):
     assert torch.equal(p2, ops.maxpool_fwd(ops.conv2d_fwd(xd, wf, ks, 1, bias=b32)))
 
 
+@pytest.mark.parametrize('case', [(1, 256, 384, 128), (2, 250, 402, 128)], ids=lambda c: 'x'.join(map(str, c)))
+def test_convolution_absorbing_the_norm_in_front_of_it(cuda, case):
+    """full_graph_stylizer_network.py:52-57 at inference: conv_b(relu(IN(conv_a(.)))) without the normalised tensor.
+    relu(a x + b) = a max(x, t) + b with t = -b / a: the kernel clamps on the way in and uses per-sample weights
+    W a; its output lacks a constant per (sample, channel), so the comparison is made behind the NEXT instance norm,
+    against the three-launch route and against the oracle."""
+    from stmi import ops
+    n, h, w, c = case
+    dtype = torch.bfloat16
+    co = 128
+    x0 = rnd((n, h, w, c), 1) * 0.5 + 0.2
+    wa = rnd((3, 3, c, c), 2, 1.0 / np.sqrt(9 * c))
+    wb = rnd((3, 3, c, co), 3, 1.0 / np.sqrt(9 * c))
+    wb[1, 1] += 0.02
+    sa, ha = rnd((c,), 4).abs() + 0.5, rnd((c,), 5)
+    sb, hb = rnd((co,), 6) + 1.5, rnd((co,), 7)
+    x0d = x0.to(cuda, dtype)
+    wpa = ops.pack_conv_weights(wa.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    wpb = ops.pack_conv_weights(wb.to(cuda, torch.float32), ops.PACK_FWD, dtype)
+    sad, had, sbd, hbd = (t.to(cuda, torch.float32) for t in (sa, ha, sb, hb))
+    need = ops.conv_absorb_norm_ws_bytes((n, h, w, c), co, dtype)
+    assert need > 0 and ops.conv_absorb_norm_ws_bytes((n, h, w, c), co, torch.float32) == 0
+    assert ops.conv_absorb_norm_ws_bytes((n, 64, 64, c), co, dtype) == 0        # planes too small for the persistent kernel
+    assert ops.conv_absorb_norm_ws_bytes((n, h, w, 64), co, dtype) == 0         # single-chunk layers are not persistent
+    ts_a = ops.conv_tile_stats_tiles((n, h, w, c), (3, 3, c, c), 1, dtype)
+    ts_b = ops.conv_tile_stats_tiles((n, h, w, c), (3, 3, c, co), 1, dtype)
+    tiles_a = torch.zeros((n, ts_a, 4, c), device=cuda)
+    xa = ops.conv2d_fwd(x0d, wpa, (3, 3, c, c), 1, tile_stats=tiles_a)          # raw output of the first convolution
+    # three launches: apply pass, convolution, next norm
+    ya, st_ref = ops.instance_norm_fwd(xa, sad, had, ops.ACT_RELU, tile_stats=tiles_a)
+    tiles_r = torch.zeros((n, ts_b, 4, co), device=cuda)
+    zr = ops.conv2d_fwd(ya, wpb, (3, 3, c, co), 1, tile_stats=tiles_r)
+    out_r, _ = ops.instance_norm_fwd(zr, sbd, hbd, ops.ACT_NONE, tile_stats=tiles_r)
+    # absorbed
+    tiles_b = torch.full((n, ts_b, 4, co), float('nan'), device=cuda)
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    z, st = ops.conv2d_fwd_absorb_norm(xa, tiles_a, sad, had, wpb, co, tiles_b, ws)
+    assert 'conv_patch_pers_kernel<__bf16, 4, 32, 4, true, true, true>' in ops.last_conv_kernel()
+    assert torch.equal(st, st_ref)
+    z2, _ = ops.conv2d_fwd_absorb_norm(xa, tiles_a, sad, had, wpb, co, tiles_b, ws)
+    assert torch.equal(z, z2)
+    out, _ = ops.instance_norm_fwd(z, sbd, hbd, ops.ACT_NONE, tile_stats=tiles_b)
+    # z differs from the plain convolution by a constant per (sample, channel), up to bf16 rounding of both
+    d = (z.float() - zr.float())
+    spread = (d - d.mean(dim=(1, 2), keepdim=True)).abs().max() / zr.float().abs().max()
+    assert spread.item() <= 3e-2, spread.item()
+    assert rel_err(out, out_r.double()) <= 3e-2
+    # the oracle, in fp32 on the host (the planes are large), from the stored raw tensor xa
+    xa32 = xa.float().cpu()
+    ya32 = torch.relu(O.instance_norm(xa32, sa.float(), ha.float()))
+    ref = O.instance_norm(O.conv2d_same(ya32, q(wb, dtype).float(), 1), sb.float(), hb.float())
+    assert rel_err(out, ref) <= TOL[dtype]
+    assert rel_err(out_r, ref) <= TOL[dtype]
+
+
 KSPLIT_CASES = [
     # n, h, w, ci, co, forced slices (None: the planner's own choice, which must be a split)
     (4, 16, 16, 512, 512, None),     # VGG conv5_x of a training batch
