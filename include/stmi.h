@@ -98,23 +98,26 @@ int stmi_pack_conv_weights_multi(const float* src_base, void* dst_base, const st
  * workspace means fewer slices or none, never an error. */
 long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
 
-/* full_graph_stylizer_network.py:52-57 (residual_block: conv -> instance norm -> ReLU -> conv -> instance norm), the
- * second convolution of a block at inference sizes WITHOUT the normalised tensor in between ever being written:
- * y = conv3x3(relu(IN(x))) - K[n][co], where x is the first convolution's raw output, in_tile_stats the tile sums
- * that convolution left (stmi_conv2d_nhwc_fwd_tile_stats; in_tiles rows per sample), in_scale (> 0, every element)
- * and in_shift the norm's parameters.  K is a constant per sample and output channel, so the call is only for a
- * convolution whose output goes into another instance norm, which removes it; tile_stats receives the tile sums of
- * y for that norm (stmi_conv2d_tile_stats_tiles rows).  in_stats [n][ci][2] receives (mean, rstd) of the absorbed
- * norm.  How: with a = scale * rstd, b = shift - mean * a, t = -b / a,  relu(a x + b) = a max(x, t) + b; the kernel
- * reads max(x, t[n][ci]) (one packed maximum per fragment register), takes t outside the image (a t + b = 0: the zero
- * padding of the normalised tensor) and multiplies with per-sample weights W a.  bf16 only, 128 input and 128
- * output channels, planes large enough for the persistent kernel (the 1080p residual layers);
- * stmi_conv2d_absorb_norm_ws_bytes: bytes of the 16-byte aligned workspace, 0 when the geometry is not supported. */
-long stmi_conv2d_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int dtype);
+/* conv_block / residual_block at inference (full_graph_stylizer_network.py:47-57: conv -> instance norm -> ReLU ->
+ * conv -> instance norm): the SECOND convolution WITHOUT the normalised tensor in between ever being written:
+ * y = conv3x3(relu(IN(x))), where x is the first convolution's raw output, in_tile_stats the tile sums that
+ * convolution left (in_tiles rows per sample), in_scale (> 0, every element) and in_shift the norm's parameters.
+ * tile_stats receives the tile sums of y for the norm behind the call (stmi_conv2d_absorb_norm_tiles rows per
+ * sample); in_stats [n][ci][2] receives (mean, rstd) of the absorbed norm.
+ * How: with a = scale * rstd, b = shift - mean * a, t = -b / a,  relu(a x + b) = a (max(x, t) - t); the kernel reads
+ * max(x, t[n][ci]) (one packed maximum per fragment register), takes t outside the image (the zero padding of the
+ * normalised tensor), multiplies with per-sample weights W a and starts its accumulators from the constant term
+ * -sum(W a t); weights, clamp values and constant come from a small launch in front (from the values as rounded to
+ * bf16, so that what the clamp flattens is an exact zero).  bf16 only: 3x3 stride 1 with 128 input and output
+ * channels on planes large enough for the persistent kernel (the 1080p residual layers), 3x3 stride 2 with 32 / 64
+ * input channels on even sides (the down-sampling layers).  stmi_conv2d_absorb_norm_ws_bytes: bytes of the 16-byte
+ * aligned workspace, 0 when the geometry is not supported. */
+long stmi_conv2d_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int stmi_conv2d_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles, const float* in_scale,
                                      const float* in_shift, float eps, float* in_stats, const void* w_packed_fwd,
                                      void* y, float* tile_stats, void* ws, int n, int h, int w, int ci, int co,
-                                     int dtype, void* stream);
+                                     int kh, int kw, int stride, int dtype, void* stream);
 
 /* vgg.py:99-103 (conv -> ReLU -> tf.nn.max_pool 2x2 / 2 'SAME'): stmi_conv2d_nhwc_fwd that also leaves the pooled
  * tensor y_pool [n, (ho+1)/2, (wo+1)/2, co] (= stmi_maxpool2x2_nhwc_fwd of y, bit for bit).  3x3 stride-1 layers

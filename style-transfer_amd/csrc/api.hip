@@ -49,10 +49,11 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
                     const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0,
                     float* ws = nullptr, long ws_floats = 0);
-long conv_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int dtype);
+long conv_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int conv_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
                               float eps, float* in_stats, const void* wp, void* y, float* tile_stats, void* ws, int n, int h,
-                              int w, int ci, int co, int dtype, hipStream_t s);
+                              int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
 long conv_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
 int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
@@ -214,23 +215,28 @@ int stmi_conv2d_nhwc_fwd_pool(const void* x, const void* w_packed_fwd, const flo
                          nullptr, 0, nullptr, 0, y_pool);
 }
 
-long stmi_conv2d_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int dtype) {
+long stmi_conv2d_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
     if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
-    const long elems = conv_absorb_norm_ws_elems(n, h, w, ci, co, dtype);
-    return elems > 0 ? (elems + 8) * (dtype == STMI_BF16 ? 2 : 4) + 16 : 0;
+    const long elems = conv_absorb_norm_ws_elems(n, h, w, ci, co, kh, kw, stride, dtype);
+    return elems > 0 ? elems * (dtype == STMI_BF16 ? 2 : 4) + 32 : 0;
+}
+
+int stmi_conv2d_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
+    return conv_absorb_norm_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
 }
 
 int stmi_conv2d_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles, const float* in_scale,
                                      const float* in_shift, float eps, float* in_stats, const void* w_packed_fwd, void* y,
-                                     float* tile_stats, void* ws, int n, int h, int w, int ci, int co, int dtype,
-                                     void* stream) {
-    if (check_conv("conv2d_nhwc_fwd_absorb_norm", n, h, w, ci, co, 3, 3, 1, dtype)) return STMI_ERR_INVALID;
+                                     float* tile_stats, void* ws, int n, int h, int w, int ci, int co, int kh, int kw,
+                                     int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_nhwc_fwd_absorb_norm", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
     if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x && in_tile_stats && in_scale && in_shift && in_stats && w_packed_fwd && y && tile_stats && ws,
                  "conv2d_nhwc_fwd_absorb_norm: null pointer");
     STMI_REQUIRE(in_tiles > 0 && (((uintptr_t)ws) & 15) == 0, "conv2d_nhwc_fwd_absorb_norm: bad tile count or unaligned workspace");
     return conv_fwd_absorb_norm_impl(x, in_tile_stats, in_tiles, in_scale, in_shift, eps, in_stats, w_packed_fwd, y,
-                                     tile_stats, ws, n, h, w, ci, co, dtype, S(stream));
+                                     tile_stats, ws, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
 }
 
 long stmi_conv2d_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad) {

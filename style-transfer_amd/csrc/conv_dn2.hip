@@ -62,8 +62,12 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 // PW: output pixels per tile row.  STATS: the block also leaves the per-tile sums of its output
 // (ConvGemmParams::tile_stats, mode 1; ONE row per block) for the instance norm behind the layer, taken from the
 // staged rows as in conv_up2_kernel.
-template <typename T, int NCH, int COF, int PW, bool STATS>
+// CLAMP (bf16, at most two chunks per pair): ConvGemmParams::clamp_t -- the launch absorbs the instance norm + ReLU
+// in front of it: pixel fragments are clamped from below by the sample's t values (one packed maximum per register),
+// rows outside the image hold t, and the weights are the sample's own (scaled) copy.
+template <typename T, int NCH, int COF, int PW, bool STATS, bool CLAMP = false>
 __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
+    static_assert(!CLAMP || (sizeof(T) == 2 && NCH <= 2), "the clamp is for bf16 pixels of 64 or 128 bytes");
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;                    // elements per 128-byte chunk
     constexpr int CO = 16 * COF;
@@ -107,6 +111,10 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
     {
         const T* in = (const T*)p.in;
         const T* zero_src = (const T*)(g_dn2_zero_page + pos);
+        // CLAMP: the sample's clamp values stand in for rows outside the image; this lane's 16-byte piece of chunk c
+        // of a pair row holds the channels (c BK + piece * EPC) mod C of one of the pair's pixels
+        const T* t_n = CLAMP ? (const T*)p.clamp_t + (long)n * C : nullptr;
+        const int sp_e = (pos ^ sub) * EPC;   // pr & 7 == sub for every piece
         const int pairs = W >> 1;
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
@@ -116,14 +124,16 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
             const bool ok = pr < NROWS && iy < H && pc < pairs;
             const T* src = in + ((long)(n * H + iy) * W + 2 * pc) * C + (pos ^ (pr & 7)) * EPC;
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
-                glds16(ok ? src + c * BK : zero_src, patch_base + c * P_CHUNK + (wave * PIECES + i) * 1024);
+            for (int c = 0; c < NCH; c++) {
+                const T* outside = CLAMP ? t_n + (c * BK + sp_e) % C : zero_src;
+                glds16(ok ? src + c * BK : outside, patch_base + c * P_CHUNK + (wave * PIECES + i) * 1024);
+            }
         }
     }
     // Weight tile of a step: rows CO x 128 bytes, swizzled like the consumers read.  The 16-byte piece a lane
     // fetches sits at source piece sp of its row: with one chunk per pair (NCH == 1) pieces 0 .. 3 are the channels
     // of tap (ky, 0) or (ky, 2) and pieces 4 .. 7 those of tap (ky, 1) (unused behind kx = 2).
-    const T* wp = (const T*)p.wp;
+    const T* wp = (const T*)p.wp + (CLAMP ? (long)n * p.w_batch_stride : 0L);
     int wrow_off[NI_W];
     bool wrow_hi[NI_W];
 #pragma unroll
@@ -152,13 +162,26 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
     stage_weights(std::integral_constant<int, 1>{});
 
     // ---------------------------------------------------------------- K loop
+    const int g = lane >> 4, r16 = lane & 15;
     f32x4 acc[COF][NF];
 #pragma unroll
-    for (int a = 0; a < COF; a++)
+    for (int a = 0; a < COF; a++) {
+        f32x4 start = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (CLAMP) start = *reinterpret_cast<const f32x4*>(p.clamp_bias + (long)n * p.Co + a * 16 + 4 * g);   // C/D rows 4 g + u
 #pragma unroll
-        for (int b = 0; b < NF; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NF; b++) acc[a][b] = start;
+    }
 
-    const int g = lane >> 4, r16 = lane & 15;
+    // CLAMP: the eight clamp values of this lane's fragment registers, per 64-byte half of a chunk: a half is 32
+    // channels of ONE pixel of the pair (all of its 32 channels, or half h of its 64), whatever the chunk
+    u32x4 tv[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
+    if constexpr (CLAMP) {
+        const T* t_n = (const T*)p.clamp_t + (long)n * C;
+        const uint4 t0 = *reinterpret_cast<const uint4*>(t_n + 8 * g);
+        const uint4 t1 = *reinterpret_cast<const uint4*>(t_n + (NCH == 1 ? 0 : 32) + 8 * g);
+        tv[0] = (u32x4){t0.x, t0.y, t0.z, t0.w};
+        tv[1] = (u32x4){t1.x, t1.y, t1.z, t1.w};
+    }
     const unsigned a_off = lds_base + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
     // pair row of this lane's first pixel column under kernel row 0, pair offset 0
     const int pr0 = (2 * wave) * PWH + r16;
@@ -196,6 +219,19 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
             for (int k = 0; k < COF; k++) lds_landed(fa[h][k]);
 #pragma unroll
             for (int f = 0; f < NF; f++) lds_landed(fb[h][f]);
+        }
+        if constexpr (CLAMP) {
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        unsigned r;
+                        asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(fb[h][f][u]), "v"(tv[h][u]));
+                        fb[h][f][u] = r;
+                    }
+                }
         }
 #pragma unroll
         for (int h = 0; h < NH; h++)
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename T, int NCH, int COF, int PW, bool STATS>
+template <typename T, int NCH, int COF, int PW, bool STATS, bool CLAMP = false>
 static int launch_dn2(const ConvGemmParams& p, hipStream_t s) {
     constexpr int PIECES = ((2 * kPH + 1) * (PW + 1) + 31) / 32;
     constexpr size_t kOperands = (size_t)kRing * 16 * COF * 128 + (size_t)NCH * 4 * PIECES * 1024;
@@ -295,9 +331,9 @@ static int launch_dn2(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kPart = (size_t)4 * 4 * 16 * COF * 4;
     constexpr size_t kLds = kOperands > kStage ? (kOperands > kPart ? kOperands : kPart) : (kStage > kPart ? kStage : kPart);
     static_assert(kLds <= 160 * 1024, "patch + weight ring exceed the CU's LDS");
-    STMI_DYN_LDS((conv_dn2_kernel<T, NCH, COF, PW, STATS>), (int)kLds, "hipFuncSetAttribute(conv_dn2_kernel)");
-    hipLaunchKernelGGL((conv_dn2_kernel<T, NCH, COF, PW, STATS>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds,
-                       s, p);
+    STMI_DYN_LDS((conv_dn2_kernel<T, NCH, COF, PW, STATS, CLAMP>), (int)kLds, "hipFuncSetAttribute(conv_dn2_kernel)");
+    hipLaunchKernelGGL((conv_dn2_kernel<T, NCH, COF, PW, STATS, CLAMP>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256),
+                       kLds, s, p);
     STMI_LAUNCH_CHECK("conv_dn2_kernel");
     return STMI_OK;
 }
@@ -319,12 +355,16 @@ static int dn2_width(int nch, int dtype) {
 static bool dn2_prepare(const ConvGemmParams& p, int dtype, ConvGemmParams& q) {
     if (STMI_ENV_SET("STMI_NO_DN2")) return false;
     const int es = dtype == STMI_BF16 ? 2 : 4;
-    if (p.in_stride != 2 || p.ntaps != 9 || p.cdiv != 0 || p.nclasses != 0 || p.w_batch_stride != 0) return false;
+    if (p.in_stride != 2 || p.ntaps != 9 || p.cdiv != 0 || p.nclasses != 0 || (p.w_batch_stride != 0 && !p.clamp_t)) return false;
     if (p.oys != 1 || p.oxs != 1 || p.oy0 != 0 || p.ox0 != 0 || p.Hs != p.Ho || p.Ws != p.Wo) return false;
     if ((p.Hi & 1) || (p.Wi & 1) || 2 * p.Ho != p.Hi || 2 * p.Wo != p.Wi) return false;   // pads below / right only
     if (p.klen != p.Ci || (2 * p.Ci * es) % 128 != 0 || (p.Co != 64 && p.Co != 128) || p.co_pad < p.Co) return false;
     const int nch = 2 * p.Ci * es / 128;
     if (dn2_width(nch, dtype) == 0) return false;
+    // the absorbed-norm form: bf16, pixels of 64 or 128 bytes, with the statistics the next norm wants
+    if (p.clamp_t && (dtype != STMI_BF16 || nch > 2 || !p.tile_stats || p.w_batch_stride <= 0 || !p.clamp_bias ||
+                      (((uintptr_t)p.clamp_t | (uintptr_t)p.clamp_bias) & 15) != 0))
+        return false;
     if (p.kpad < p.Ci || (p.kpad * es) % 16 != 0) return false;
     for (int t = 0; t < 9; t++)
         if (p.taps[t].dy != t / 3 || p.taps[t].dx != t % 3 || p.taps[t].widx != t) return false;
@@ -342,8 +382,10 @@ static bool dn2_prepare(const ConvGemmParams& p, int dtype, ConvGemmParams& q) {
 // Statistics rows per sample this kernel leaves for the launch p (one per block), 0 when p is not its layer.
 int conv_dn2_tile_stats_tiles(const ConvGemmParams& p, int dtype) {
     ConvGemmParams q;
-    ConvGemmParams plain = p;
+    ConvGemmParams plain = p;   // a question about the geometry only
     plain.tile_stats = nullptr;
+    plain.clamp_t = nullptr;
+    plain.w_batch_stride = 0;
     if (!dn2_prepare(plain, dtype, q)) return 0;
     return (int)(q.pt_div[1] * q.pt_div[2]);
 }
@@ -356,8 +398,14 @@ bool try_launch_conv_dn2(const ConvGemmParams& p, int dtype, hipStream_t s, int*
     const int nch = 2 * p.Ci * es / 128;
     const int cof = p.Co / 16;
     if (name)
-        snprintf(name, name_len, "void stmi::conv_dn2_kernel<%s, %d, %d, %d, %s>(stmi::ConvGemmParams)",
-                 dtype == STMI_BF16 ? "__bf16" : "float", nch, cof, dn2_width(nch, dtype), p.tile_stats ? "true" : "false");
+        snprintf(name, name_len, "void stmi::conv_dn2_kernel<%s, %d, %d, %d, %s, %s>(stmi::ConvGemmParams)",
+                 dtype == STMI_BF16 ? "__bf16" : "float", nch, cof, dn2_width(nch, dtype), p.tile_stats ? "true" : "false",
+                 p.clamp_t ? "true" : "false");
+    if (p.clamp_t) {
+        if (nch == 1) *rc = cof == 4 ? launch_dn2<bf16_t, 1, 4, 32, true, true>(q, s) : launch_dn2<bf16_t, 1, 8, 32, true, true>(q, s);
+        else *rc = cof == 4 ? launch_dn2<bf16_t, 2, 4, 32, true, true>(q, s) : launch_dn2<bf16_t, 2, 8, 32, true, true>(q, s);
+        return true;
+    }
     if (dtype == STMI_BF16) {
         if (nch == 1) *rc = cof == 4 ? launch_dn2_s<bf16_t, 1, 4, 32>(q, s) : launch_dn2_s<bf16_t, 1, 8, 32>(q, s);
         else *rc = cof == 4 ? launch_dn2_s<bf16_t, 2, 4, 32>(q, s) : launch_dn2_s<bf16_t, 2, 8, 32>(q, s);

@@ -487,50 +487,75 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
 
 int in_stats_from_tiles_impl(const float* tiles, int ts, float* stats, float eps, int n, int c, hipStream_t s);   // instnorm.hip
 int in_absorb_prep_impl(const float* stats, const float* scale, const float* shift, const void* wp, void* clamp_t,
-                        void* wps, int n, int c, int kpad, long welems, int dtype, hipStream_t s);
+                        void* wps, float* bias, int n, int c, int kpad, int rows_pad, int taps, int co, int dtype,
+                        hipStream_t s);
 
-// 3x3 stride-1 convolution of relu(IN(x)) given x, the tile sums of x (from the convolution that wrote it) and the
-// norm's scale (> 0) / shift -- without the normalised tensor ever being written: see ConvGemmParams::clamp_t.  The
-// result lacks a per-(sample, output channel) constant, which only a following instance norm makes harmless.
-// ws: n * ci + n * packed-weight elements of the compute type.  stats: receives (mean, rstd) of the absorbed norm.
-static bool absorb_setup(ConvGemmParams& p, int n, int h, int w, int ci, int co, int dtype) {
+// 3x3 convolution (stride 1 or 2) of relu(IN(x)) given x, the tile sums of x (from the convolution that wrote it)
+// and the norm's scale (> 0) / shift -- without the normalised tensor ever being written: see
+// ConvGemmParams::clamp_t.  ws: n * ci clamp values + n packed-weight copies of the compute type + n * co floats
+// of constant terms.  stats: receives (mean, rstd) of the absorbed norm.
+static bool absorb_setup(ConvGemmParams& p, int n, int h, int w, int ci, int co, int stride, int dtype) {
     clear_params(p);
-    if (setup_fwd(p, n, h, w, ci, co, 3, 3, 1)) return false;
+    if (setup_fwd(p, n, h, w, ci, co, 3, 3, stride)) return false;
     p.row_store_ok = co % (dtype == STMI_BF16 ? 8 : 4) == 0;
+    // the questions the kernels' launchers ask, on a launch with stand-in pointers
+    p.clamp_t = reinterpret_cast<const void*>(16);
+    p.clamp_bias = reinterpret_cast<const float*>(16);
+    p.tile_stats = reinterpret_cast<float*>(16);
+    p.tile_stats_mode = 1;
+    p.w_batch_stride = (long)p.ntaps * p.co_pad * p.kpad;
     return true;
 }
 
-long conv_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int dtype) {
+// statistics rows per sample of the output, 0: the geometry has no absorbing kernel
+static int absorb_tiles(ConvGemmParams& p, int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (dtype != STMI_BF16 || kh != 3 || kw != 3 || !absorb_setup(p, n, h, w, ci, co, stride, dtype)) return 0;
+    if (stride == 2) {
+        const int ts = conv_dn2_tile_stats_tiles(p, dtype);
+        p.tile_stats_ts = ts;
+        return ts > 0 && 2 * ci * 2 / 128 <= 2 ? ts : 0;
+    }
+    if (stride != 1 || ci != 128 || p.co_pad != 128 || !conv_patch_stats_free(p, dtype)) return 0;
+    p.tile_stats_ts = conv_patch_tiles_per_sample(p, dtype, 1);
+    return p.tile_stats_ts;
+}
+
+long conv_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
     ConvGemmParams p;
-    if (dtype != STMI_BF16 || ci != 128 || !absorb_setup(p, n, h, w, ci, co, dtype)) return 0;
-    // the same questions try_launch_conv_patch asks, on a launch with stand-in pointers
-    p.clamp_t = reinterpret_cast<const void*>(16);
-    p.w_batch_stride = (long)p.ntaps * p.co_pad * p.kpad;
-    if (conv_patch_tiles_per_sample(p, dtype, 1) <= 0 || !conv_patch_stats_free(p, dtype) || p.co_pad != 128) return 0;
-    return (long)n * ci + (long)n * p.w_batch_stride;
+    if (absorb_tiles(p, n, h, w, ci, co, kh, kw, stride, dtype) <= 0) return 0;
+    // clamp values, the samples' weight copies, and the fp32 bias rows (two elements of the compute type each)
+    return ((long)n * ci + 7) / 8 * 8 + (long)n * p.w_batch_stride + 2 * ((long)n * co + 3) / 4 * 4;
+}
+
+int conv_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    ConvGemmParams p;
+    return absorb_tiles(p, n, h, w, ci, co, kh, kw, stride, dtype);
 }
 
 int conv_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
                               float eps, float* in_stats, const void* wp, void* y, float* tile_stats, void* ws, int n, int h,
-                              int w, int ci, int co, int dtype, hipStream_t s) {
+                              int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s) {
     ConvGemmParams p;
-    STMI_REQUIRE(conv_absorb_norm_ws_elems(n, h, w, ci, co, dtype) > 0 && absorb_setup(p, n, h, w, ci, co, dtype),
+    STMI_REQUIRE(absorb_tiles(p, n, h, w, ci, co, kh, kw, stride, dtype) > 0,
                  "conv absorb norm: this geometry is not supported (stmi_conv2d_absorb_norm_ws_bytes returned 0)");
-    const long welems = (long)p.ntaps * p.co_pad * p.kpad;
+    const long welems = p.w_batch_stride;
     const size_t es = dtype == STMI_BF16 ? 2 : 4;
     void* clamp_t = ws;
-    void* wps = static_cast<char*>(ws) + (((size_t)n * ci * es + 15) / 16) * 16;
+    char* wps = static_cast<char*>(ws) + (((long)n * ci + 7) / 8 * 8) * es;
+    float* bias = reinterpret_cast<float*>(wps + (((long)n * welems * es + 15) / 16) * 16);
     int rc = in_stats_from_tiles_impl(in_tiles, in_ts, in_stats, eps, n, ci, s);
     if (rc) return rc;
-    rc = in_absorb_prep_impl(in_stats, in_scale, in_shift, wp, clamp_t, wps, n, ci, p.kpad, welems, dtype, s);
+    rc = in_absorb_prep_impl(in_stats, in_scale, in_shift, wp, clamp_t, wps, bias, n, ci, p.kpad, p.co_pad, p.ntaps, co, dtype, s);
     if (rc) return rc;
     p.in = x; p.wp = wps; p.out = y;
-    p.clamp_t = clamp_t; p.w_batch_stride = welems;
-    p.tile_stats = tile_stats; p.tile_stats_ts = conv_patch_tiles_per_sample(p, dtype, 1); p.tile_stats_mode = 1;
+    p.clamp_t = clamp_t;
+    p.clamp_bias = bias;
+    p.tile_stats = tile_stats;
     set_row_store(p, dtype);
     rc = STMI_OK;
-    STMI_REQUIRE(try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel)),
-                 "conv absorb norm: the tensors must be 16-byte aligned");
+    const bool taken = stride == 2 ? try_launch_conv_dn2(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))
+                                   : try_launch_conv_patch(p, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel));
+    STMI_REQUIRE(taken, "conv absorb norm: the tensors must be 16-byte aligned");
     return rc;
 }
 

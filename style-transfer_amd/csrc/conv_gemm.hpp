@@ -40,9 +40,10 @@ struct ConvGemmParams {
     // raw input of an instance norm + ReLU that this convolution absorbs.  With a = scale * rstd > 0, b = shift -
     // mean * a, t = -b / a:  relu(a x + b) = a * max(x, t) + b, so the launch reads max(x, clamp_t[n][ci]) (one packed
     // max per fragment register), takes t for taps outside the image (a t + b = 0: the zero padding of the
-    // normalised tensor) and multiplies with per-sample weights W * a (w_batch_stride apart).  What is left out, the
-    // per-(sample, output channel) constant sum(W b), is removed by the instance norm that follows the convolution.
+    // normalised tensor) and multiplies with per-sample weights W * a (w_batch_stride apart).  The constant term
+    // sum(W b) = -sum(W a t) per (sample, output channel) is what the accumulators start from: clamp_bias[n][Co].
     const void* clamp_t;
+    const float* clamp_bias;
     Tap taps[kMaxTaps];
     // Several output sub-grids in ONE launch (the stride^2 parity classes of a strided backward-data /
     // transposed convolution; producer/consumer kernel only).  nclasses == 0: the fields above describe the

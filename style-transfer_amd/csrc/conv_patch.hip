@@ -946,9 +946,13 @@ __global__ __launch_bounds__(512) void conv_patch_pers_kernel(const ConvGemmPara
         for (int it = 0; it < my_tiles; it++) {
             const TilePos tp0 = tile_pos(it);
 #pragma unroll
-            for (int a = 0; a < TC; a++)
+            for (int a = 0; a < TC; a++) {
+                f32x4 start = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (CLAMP)   // the constant term of the absorbed norm; C/D rows 4 g + u of channel fragment a
+                    start = *reinterpret_cast<const f32x4*>(p.clamp_bias + (long)tp0.n * p.Co + tp0.co0 + wc * (TC * 16) + a * 16 + 4 * g);
 #pragma unroll
-                for (int b = 0; b < TP; b++) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < TP; b++) acc[a][b] = start;
+            }
 #pragma unroll
             for (int tc = 0; tc < TC; tc++) fa[1][tc] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
@@ -1386,8 +1390,8 @@ bool try_launch_conv_patch(const ConvGemmParams& p_in, int dtype, hipStream_t s,
     if (p.clamp_t) {
         // the absorbed-norm form exists as the persistent bf16 kernel with the wave-private epilogue and statistics
         if (dtype != STMI_BF16 || co != 128 || !patch_wepi(p, dtype, co) || !p.tile_stats || p.tile_stats_mode != 1 ||
-            !patch_stats_two_rows(p, dtype) || p.Ci > 128 || p.w_batch_stride <= 0 || ((uintptr_t)p.clamp_t & 15) != 0 ||
-            p.pool_out || p.ksplit_ws)
+            !patch_stats_two_rows(p, dtype) || p.Ci > 128 || p.w_batch_stride <= 0 || !p.clamp_bias || p.Co % 128 != 0 ||
+            (((uintptr_t)p.clamp_t | (uintptr_t)p.clamp_bias) & 15) != 0 || p.pool_out || p.ksplit_ws)
             return false;
         if (name)
             snprintf(name, name_len, "void stmi::conv_patch_pers_kernel<__bf16, 4, %d, 4, true, true, true>(stmi::ConvGemmParams)",

@@ -175,41 +175,51 @@ def conv2d_fwd_pool(x, w_packed, kshape, stride, bias=None, relu=True, out=None,
     return y, yp
 
 
-def conv_absorb_norm_ws_bytes(x_shape, co, dtype):
+def conv_absorb_norm_ws_bytes(x_shape, kshape, stride, dtype):
     """Bytes of workspace conv2d_fwd_absorb_norm needs for this geometry; 0: not supported."""
-    n, h, w, ci = x_shape
-    return int(_lib.load().stmi_conv2d_absorb_norm_ws_bytes(n, h, w, ci, co, _DT[dtype]))
+    n, h, w, _ = x_shape
+    kh, kw, ci, co = kshape
+    return int(_lib.load().stmi_conv2d_absorb_norm_ws_bytes(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
 
 
-def conv2d_fwd_absorb_norm(x, in_tile_stats, in_scale, in_shift, w_packed, co, tile_stats, ws, in_stats=None, out=None,
-                           eps=None):
-    """conv3x3(relu(IN(x))) minus a per-(sample, channel) constant, for a convolution whose output feeds another
-    instance norm: x is the raw output of the convolution in front (in_tile_stats: the tile sums it left),
+def conv_absorb_norm_tiles(x_shape, kshape, stride, dtype):
+    """Rows per sample of the tile sums conv2d_fwd_absorb_norm leaves for the norm behind it."""
+    n, h, w, _ = x_shape
+    kh, kw, ci, co = kshape
+    return int(_lib.load().stmi_conv2d_absorb_norm_tiles(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
+def conv2d_fwd_absorb_norm(x, in_tile_stats, in_scale, in_shift, w_packed, kshape, stride, tile_stats, ws, in_stats=None,
+                           out=None, eps=None):
+    """conv3x3(relu(IN(x))): x is the raw output of the convolution in front (in_tile_stats: the tile sums it left),
     in_scale (> 0) / in_shift the absorbed norm's parameters; the normalised tensor is never written.
-    Returns (y, in_stats); tile_stats receives the tile sums of y."""
-    n, h, w, ci = x.shape
+    Returns (y, in_stats); tile_stats receives the tile sums of y for the norm behind it."""
+    n, h, w, c = x.shape
+    kh, kw, ci, co = kshape
+    assert c == ci, (c, ci)
     _chk(x, 'x')
     _chk(in_tile_stats, 'in_tile_stats', torch.float32)
     assert in_tile_stats.dim() == 4 and in_tile_stats.shape[0] == n and in_tile_stats.shape[2:] == (4, ci), tuple(in_tile_stats.shape)
     _chk(in_scale, 'in_scale', torch.float32, (ci,))
     _chk(in_shift, 'in_shift', torch.float32, (ci,))
-    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(3, 3, ci, co, PACK_FWD),))
-    need = conv_absorb_norm_ws_bytes(x.shape, co, x.dtype)
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, ci, co, PACK_FWD),))
+    need = conv_absorb_norm_ws_bytes(x.shape, kshape, stride, x.dtype)
     if need == 0:
         raise ValueError('conv2d_fwd_absorb_norm: geometry not supported')
     _chk(ws, 'ws', torch.uint8)
     if ws.numel() < need:
         raise ValueError('conv2d_fwd_absorb_norm: workspace of %d bytes, %d needed' % (ws.numel(), need))
-    ts = conv_tile_stats_tiles(x.shape, (3, 3, ci, co), 1, x.dtype)
+    ts = conv_absorb_norm_tiles(x.shape, kshape, stride, x.dtype)
     _chk(tile_stats, 'tile_stats', torch.float32, (n, ts, 4, co))
-    y = torch.empty((n, h, w, co), dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, (n, h, w, co))
+    oshape = (n, same_out(h, stride), same_out(w, stride), co)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
     st = torch.empty((n, ci, 2), dtype=torch.float32, device=x.device) if in_stats is None else _chk(in_stats, 'in_stats', torch.float32, (n, ci, 2))
     _conv_call('stmi_conv2d_nhwc_fwd_absorb_norm', (x.data_ptr(), in_tile_stats.data_ptr(), in_tile_stats.shape[1],
                                                     in_scale.data_ptr(), in_shift.data_ptr(),
                                                     float(IN_EPS if eps is None else eps), st.data_ptr(),
                                                     w_packed.data_ptr(), y.data_ptr(), tile_stats.data_ptr(), ws.data_ptr(),
-                                                    n, h, w, ci, co, _dt(x)),
-               co, n * h * w, ci, 9, 1)
+                                                    n, h, w, ci, co, kh, kw, stride, _dt(x)),
+               co, n * oshape[1] * oshape[2], ci, kh * kw, stride)
     return y, st
 
 

@@ -234,24 +234,34 @@ class StylizerNet:
         return [v.detach().cpu().numpy().copy() for v in self.views]
 
     def _plan_absorb(self):
-        """Inference: where the second convolution of a residual block can absorb the norm + ReLU in front of it
-        (ops.conv2d_fwd_absorb_norm: bf16, 1080p-sized planes, every scale of that norm positive), the apply pass
-        of the block's first norm is not run at all.  Decided from the parameters: call again after changing them."""
+        """Inference: where a convolution can absorb the norm + ReLU in front of it (ops.conv2d_fwd_absorb_norm: bf16,
+        the second convolution of a residual block on 1080p-sized planes, the down-sampling layers; every scale of
+        that norm positive; the normalised tensor needed by nobody else), the norm's apply pass is not run at all.
+        b.absorb_ws is set on the block whose norm the NEXT block absorbs.  Decided from the parameters: called again
+        after they change."""
         for b in self.blocks:
             b.absorb_ws = None
         if self.training or not tuning.ABSORB_NORM or not tuning.TILE_STATS:
             return
         for i, b in enumerate(self.blocks[:-1]):
             nb = self.blocks[i + 1]
-            if b.role != 'a' or nb.role != 'b' or b.tile_stats is None or nb.tile_stats is None:
+            # the next block must read the tensor for its convolution only (a residual block's first convolution
+            # also keeps it as the skip tensor), and leave tile sums for its own norm
+            if nb.role == 'a' or b.tile_stats is None or nb.tile_stats is None or b.act != ops.ACT_RELU:
                 continue
-            if b.act != ops.ACT_RELU or nb.kind != 'conv' or nb.rows is not None or nb.k != 3 or nb.s != 1:
+            if nb.kind != 'conv' or nb.rows is not None or nb.k != 3:
                 continue
-            need = ops.conv_absorb_norm_ws_bytes((self.n, b.out_h, b.out_w, b.co), nb.co, self.dtype)
-            if need and bool((b.scale > 0).all()):
+            shape = (self.n, b.out_h, b.out_w, b.co)
+            need = ops.conv_absorb_norm_ws_bytes(shape, nb.kshape, nb.s, self.dtype)
+            if need == 0 or ops.conv_absorb_norm_tiles(shape, nb.kshape, nb.s, self.dtype) != nb.tile_stats.shape[1]:
+                continue
+            if bool((b.scale > 0).all()):
                 if self._absorb_ws is None or self._absorb_ws.numel() < need:
                     self._absorb_ws = torch.empty(need, dtype=torch.uint8, device=b.scale.device)
-                b.absorb_ws = self._absorb_ws      # the blocks run in stream order: one workspace serves them all
+                b.absorb_ws = True
+        for b in self.blocks:      # the blocks run in stream order: one workspace serves them all
+            if b.absorb_ws:
+                b.absorb_ws = self._absorb_ws
 
     def repack(self):
         """Refreshes the K-contiguous weight copies after the fp32 masters changed."""
@@ -321,17 +331,17 @@ class StylizerNet:
                 ops.rows_to_pixels_sum(b.rows_buf, b.co, b.k, -b.pad_left, out=conv_out)
             elif absorbed is not None:
                 # cur is the raw output of the block's first convolution: its norm + ReLU happen on the way in
-                ops.conv2d_fwd_absorb_norm(cur, absorbed.tile_stats, absorbed.scale, absorbed.shift, b.wp_fwd, b.co,
-                                           b.tile_stats, absorbed.absorb_ws, in_stats=absorbed.stats, out=conv_out)
+                ops.conv2d_fwd_absorb_norm(cur, absorbed.tile_stats, absorbed.scale, absorbed.shift, b.wp_fwd, b.kshape,
+                                           b.s, b.tile_stats, absorbed.absorb_ws, in_stats=absorbed.stats, out=conv_out)
                 absorbed = None
             else:
                 ops.conv2d_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             if b.role == 'a':
                 skip = cur
-                if b.absorb_ws is not None:
-                    absorbed = b
-                    cur = conv_out
-                    continue
+            if b.absorb_ws is not None:     # the next block's convolution applies this norm + ReLU on its way in
+                absorbed = b
+                cur = conv_out
+                continue
             if i == last and out_u8 is not None:
                 ops.instance_norm_stats(conv_out, ws=self.ws, stats=b.stats)
                 ops.instance_norm_apply_u8(conv_out, b.stats, b.scale, b.shift, b.act, out=out_u8)

@@ -437,9 +437,9 @@ def test_inference_1080p_batch16_bf16(cuda):
     assert psnr(batch_out[1:2], ref) >= 40.0
 
 
-def test_absorbed_residual_norms_equal_the_apply_passes(cuda, monkeypatch):
-    """At inference sizes the second convolution of a residual block absorbs the norm + ReLU in front of it
-    (full_graph_stylizer_network.py:52-57 without the normalised tensor in between).  Same picture as the route
+def test_absorbed_norms_equal_the_apply_passes(cuda, monkeypatch):
+    """At inference sizes the second convolution of a residual block and the two down-sampling convolutions absorb
+    the norm + ReLU in front of them (full_graph_stylizer_network.py:47-57 without the normalised tensors).  Same picture as the route
     with the apply passes, within bf16; a non-positive scale in such a norm switches the block back."""
     from stmi import tuning
     from stmi.stylizer import StylizerNet
@@ -448,7 +448,8 @@ def test_absorbed_residual_norms_equal_the_apply_passes(cuda, monkeypatch):
     frames = torch.rand((2, 1024, 1536, 3), generator=g, dtype=torch.float32).to(cuda)
     net = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)
     absorbing = [i for i, b in enumerate(net.blocks) if b.absorb_ws is not None]
-    assert len(absorbing) == 5 and all(net.blocks[i].role == 'a' for i in absorbing)
+    # the two layers in front of the down-sampling convolutions and the first layer of each residual block
+    assert absorbing == [0, 1, 3, 5, 7, 9, 11] and all(net.blocks[i].role == 'a' for i in absorbing[2:])
     out = net.forward(frames).clone()
     monkeypatch.setattr(tuning, 'ABSORB_NORM', False)
     plain = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)
@@ -457,12 +458,12 @@ def test_absorbed_residual_norms_equal_the_apply_passes(cuda, monkeypatch):
     assert psnr(out.cpu(), ref.cpu()) >= 45.0
     monkeypatch.setattr(tuning, 'ABSORB_NORM', True)
     flipped = [np.array(p, copy=True) for p in params]
-    scale_index = 3 * absorbing[0] + 2                 # W, shift, scale per block, in creation order
+    scale_index = 3 * absorbing[2] + 2                 # W, shift, scale per block, in creation order
     assert flipped[scale_index].shape == (128,)
     flipped[scale_index][5] = -0.5
     net.load_params(flipped)
     net.repack()
-    assert net.blocks[absorbing[0]].absorb_ws is None and net.blocks[absorbing[1]].absorb_ws is not None
+    assert net.blocks[absorbing[2]].absorb_ws is None and net.blocks[absorbing[3]].absorb_ws is not None
     plain.load_params(flipped)
     plain.repack()
     assert psnr(net.forward(frames).cpu(), plain.forward(frames).cpu()) >= 45.0
