@@ -221,25 +221,38 @@ __global__ __launch_bounds__(256) void conv_dn2_kernel(const ConvGemmParams p) {
             for (int f = 0; f < NF; f++) lds_landed(fb[h][f]);
         }
         if constexpr (CLAMP) {
+            // a pixel fragment is clamped behind the first product of the fragment before it: all but the first
+            // four packed maxima of a step run under matrix work
+            auto clamp = [&](int h, int f) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    unsigned r;
+                    asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(fb[h][f][u]), "v"(tv[h][u]));
+                    fb[h][f][u] = r;
+                }
+            };
+            clamp(0, 0);
 #pragma unroll
             for (int h = 0; h < NH; h++)
 #pragma unroll
-                for (int f = 0; f < NF; f++) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        unsigned r;
-                        asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(fb[h][f][u]), "v"(tv[h][u]));
-                        fb[h][f][u] = r;
-                    }
-                }
-        }
-#pragma unroll
-        for (int h = 0; h < NH; h++)
-#pragma unroll
-            for (int k = 0; k < COF; k++)
-#pragma unroll
                 for (int f = 0; f < NF; f++)
-                    Mma<T>::mma(__builtin_bit_cast(frag, fa[h][k]), __builtin_bit_cast(frag, fb[h][f]), acc[k][f]);
+#pragma unroll
+                    for (int k = 0; k < COF; k++) {
+                        Mma<T>::mma(__builtin_bit_cast(frag, fa[h][k]), __builtin_bit_cast(frag, fb[h][f]), acc[k][f]);
+                        if (k == 0) {
+                            if (f + 1 < NF) clamp(h, f + 1);
+                            else if (h + 1 < NH) clamp(h + 1, 0);
+                        }
+                    }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int k = 0; k < COF; k++)
+#pragma unroll
+                    for (int f = 0; f < NF; f++)
+                        Mma<T>::mma(__builtin_bit_cast(frag, fa[h][k]), __builtin_bit_cast(frag, fb[h][f]), acc[k][f]);
+        }
     });
 
     // ---------------------------------------------------------------- epilogue

@@ -905,35 +905,41 @@ int in_stats_from_tiles_impl(const float* tiles, int ts, float* stats, float eps
 // packed weights [taps][rows][kpad] (K = input channel, contiguous) scaled by a along K, and the constant term
 // bias[n][co] = -sum over taps and channels of W' t -- from the ROUNDED weights and clamp values, the ones the kernel
 // multiplies, so that a region the clamp flattens comes out as the exact zero of the normalised tensor.  scale > 0.
-// grid (bx + ceil(co / 256), n): the first bx blocks of a sample scale the weights, the others sum the bias.
+// Two launches: weights and clamp values, then one wave per (output channel, sample) for the constant terms.
 template <typename T>
 __global__ __launch_bounds__(256) void in_absorb_prep_kernel(const float* __restrict__ stats, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const T* __restrict__ wp,
-                                                             T* __restrict__ clamp_t, T* __restrict__ wps,
-                                                             float* __restrict__ bias, int C, int kpad, int rows_pad, int taps,
-                                                             int co, int bx) {
+                                                             T* __restrict__ clamp_t, T* __restrict__ wps, int C, int kpad,
+                                                             long welems) {
     const int n = blockIdx.y;
     const float* st = stats + (long)n * C * 2;
-    const long welems = (long)taps * rows_pad * kpad;
-    auto a_of = [&](int k) { return scale[k] * st[2 * k + 1]; };
-    auto t_of = [&](int k) { return to_f32<T>(from_f32<T>(fminf(fmaxf(st[2 * k] - shift[k] / a_of(k), -1e30f), 1e30f))); };
-    if ((int)blockIdx.x < bx) {
-        for (long e = blockIdx.x * 256L + threadIdx.x; e < welems; e += (long)bx * 256) {
-            const int k = (int)(e % kpad);
-            wps[(long)n * welems + e] = from_f32<T>(k < C ? to_f32<T>(wp[e]) * a_of(k) : 0.f);
-        }
-        if (blockIdx.x == 0)
-            for (int c = threadIdx.x; c < C; c += 256) clamp_t[(long)n * C + c] = from_f32<T>(t_of(c));   // far below the fp16-NaN patterns
-        return;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < welems; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % kpad);
+        wps[(long)n * welems + e] = from_f32<T>(k < C ? to_f32<T>(wp[e]) * (scale[k] * st[2 * k + 1]) : 0.f);
     }
-    const int o = ((int)blockIdx.x - bx) * 256 + threadIdx.x;
-    if (o >= co) return;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float a = scale[c] * st[2 * c + 1];
+            clamp_t[(long)n * C + c] = from_f32<T>(fminf(fmaxf(st[2 * c] - shift[c] / a, -1e30f), 1e30f));   // far below the fp16-NaN patterns
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void in_absorb_bias_kernel(const T* __restrict__ clamp_t, const T* __restrict__ wps,
+                                                            float* __restrict__ bias, int C, int kpad, int rows_pad, int taps,
+                                                            int co) {
+    const int o = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const T* w_n = wps + (long)n * taps * rows_pad * kpad;
+    const T* t_n = clamp_t + (long)n * C;
     float acc = 0.f;
     for (int tap = 0; tap < taps; tap++) {
-        const T* row = wp + ((long)tap * rows_pad + o) * kpad;
-        for (int k = 0; k < C; k++) acc += to_f32<T>(from_f32<T>(to_f32<T>(row[k]) * a_of(k))) * t_of(k);
+        const T* row = w_n + ((long)tap * rows_pad + o) * kpad;
+        for (int k = lane; k < C; k += 64) acc += to_f32<T>(row[k]) * to_f32<T>(t_n[k]);
     }
-    bias[(long)n * co + o] = -acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) bias[(long)n * co + o] = -acc;
 }
 
 int in_absorb_prep_impl(const float* stats, const float* scale, const float* shift, const void* wp, void* clamp_t,
@@ -941,14 +947,18 @@ int in_absorb_prep_impl(const float* stats, const float* scale, const float* shi
                         hipStream_t s) {
     const long welems = (long)taps * rows_pad * kpad;
     const int bx = (int)((welems + 1023) / 1024 > 256 ? 256 : (welems + 1023) / 1024 > 0 ? (welems + 1023) / 1024 : 1);
-    const dim3 grid(bx + (co + 255) / 256, n);
-    if (dtype == STMI_BF16)
-        hipLaunchKernelGGL(in_absorb_prep_kernel<bf16_t>, grid, dim3(256), 0, s, stats, scale, shift, (const bf16_t*)wp,
-                           (bf16_t*)clamp_t, (bf16_t*)wps, bias, c, kpad, rows_pad, taps, co, bx);
-    else
-        hipLaunchKernelGGL(in_absorb_prep_kernel<float>, grid, dim3(256), 0, s, stats, scale, shift, (const float*)wp,
-                           (float*)clamp_t, (float*)wps, bias, c, kpad, rows_pad, taps, co, bx);
-    STMI_LAUNCH_CHECK("in_absorb_prep_kernel");
+    if (dtype == STMI_BF16) {
+        hipLaunchKernelGGL(in_absorb_prep_kernel<bf16_t>, dim3(bx, n), dim3(256), 0, s, stats, scale, shift, (const bf16_t*)wp,
+                           (bf16_t*)clamp_t, (bf16_t*)wps, c, kpad, welems);
+        hipLaunchKernelGGL(in_absorb_bias_kernel<bf16_t>, dim3(co, n), dim3(64), 0, s, (const bf16_t*)clamp_t, (const bf16_t*)wps,
+                           bias, c, kpad, rows_pad, taps, co);
+    } else {
+        hipLaunchKernelGGL(in_absorb_prep_kernel<float>, dim3(bx, n), dim3(256), 0, s, stats, scale, shift, (const float*)wp,
+                           (float*)clamp_t, (float*)wps, c, kpad, welems);
+        hipLaunchKernelGGL(in_absorb_bias_kernel<float>, dim3(co, n), dim3(64), 0, s, (const float*)clamp_t, (const float*)wps,
+                           bias, c, kpad, rows_pad, taps, co);
+    }
+    STMI_LAUNCH_CHECK("in_absorb_prep kernels");
     return STMI_OK;
 }
 
