@@ -190,6 +190,16 @@ int stmi_conv2d_to3_supported(int k, int ci, int dtype);
 int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const void* addend, void* y,
                              int n, int h, int w, int ci, int k, int dtype, void* stream);
 
+/* stmi_conv2d_to3_nhwc_fwd absorbing the instance norm + ReLU in front of it, as stmi_conv2d_nhwc_fwd_absorb_norm
+ * does for the 3x3 layers (full_graph_stylizer_network.py:76-78: the last up-sampling block's norm and the 9x9
+ * output layer): x is the raw output of the layer in front, in_tile_stats the tile sums it left; the patch goes to
+ * LDS already clamped.  bf16, 9x9, 32 input channels; no tile sums of y (three channels: its norm runs its own
+ * pass).  stmi_conv2d_to3_absorb_norm_ws_bytes: bytes of the 16-byte aligned workspace, 0: not supported. */
+long stmi_conv2d_to3_absorb_norm_ws_bytes(int n, int h, int w, int ci, int k, int dtype);
+int stmi_conv2d_to3_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles, const float* in_scale,
+                                         const float* in_shift, float eps, float* in_stats, const void* w_packed_rowout,
+                                         void* y, void* ws, int n, int h, int w, int ci, int k, int dtype, void* stream);
+
 /* Gradient w.r.t. the input of a k x k stride-1 convolution that WRITES three channels (the stylizer's
  * last layer, full_graph_stylizer_network.py:78): dy [n,h,w,3] in dtype -> dx [n,h,w,ci]; W packed with
  * STMI_PACK_DGRAD_RGB.  Built for (k, ci) = (9, 32). */

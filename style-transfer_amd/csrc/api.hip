@@ -54,6 +54,10 @@ int conv_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, 
 int conv_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
                               float eps, float* in_stats, const void* wp, void* y, float* tile_stats, void* ws, int n, int h,
                               int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s);
+long conv_to3_absorb_norm_ws_elems(int n, int ci, int k, int dtype);
+int conv_to3_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
+                              float eps, float* in_stats, const void* wq, void* y, void* ws, int n, int h, int w, int ci, int k,
+                              int dtype, hipStream_t s);
 long conv_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad);
 int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_dgrad_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
@@ -322,6 +326,24 @@ int stmi_conv2d_to3_nhwc_fwd(const void* x, const void* w_packed_rowout, const v
     if (n == 0) return STMI_OK;  // an empty batch has no buffers
     STMI_REQUIRE(x && w_packed_rowout && y, "conv2d_to3_nhwc_fwd: null pointer");
     return conv_to3_impl(x, w_packed_rowout, addend, y, n, h, w, ci, k, dtype, S(stream));
+}
+
+long stmi_conv2d_to3_absorb_norm_ws_bytes(int n, int h, int w, int ci, int k, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || k <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
+    const long elems = conv_to3_absorb_norm_ws_elems(n, ci, k, dtype);
+    return elems > 0 ? elems * 2 + 32 : 0;
+}
+
+int stmi_conv2d_to3_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles, const float* in_scale,
+                                         const float* in_shift, float eps, float* in_stats, const void* w_packed_rowout,
+                                         void* y, void* ws, int n, int h, int w, int ci, int k, int dtype, void* stream) {
+    if (check_conv("conv2d_to3_nhwc_fwd_absorb_norm", n, h, w, ci, 3, k, k, 1, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
+    STMI_REQUIRE(x && in_tile_stats && in_scale && in_shift && in_stats && w_packed_rowout && y && ws,
+                 "conv2d_to3_nhwc_fwd_absorb_norm: null pointer");
+    STMI_REQUIRE(in_tiles > 0 && (((uintptr_t)ws) & 15) == 0, "conv2d_to3_nhwc_fwd_absorb_norm: bad tile count or unaligned workspace");
+    return conv_to3_absorb_norm_impl(x, in_tile_stats, in_tiles, in_scale, in_shift, eps, in_stats, w_packed_rowout, y, ws,
+                                     n, h, w, ci, k, dtype, S(stream));
 }
 
 int stmi_conv2d_nhwc_dgrad(const void* dy, const void* w_packed_dgrad, void* dx, const void* relu_mask,

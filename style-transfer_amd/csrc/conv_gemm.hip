@@ -559,6 +559,34 @@ int conv_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, c
     return rc;
 }
 
+// The k x k layer INTO three channels (conv_to3.hip) absorbing the norm + ReLU in front of it: bf16, 9 x 9, 32 input
+// channels.  ws as above, with 32 constant terms per sample (one per (kx, co) row of the packed weights).
+int conv_to3_supported(int k, int ci, int dtype);
+int conv_to3_clamp_impl(const void* x, const void* wq_samples, long w_stride, const void* clamp_t, const float* bias_rows,
+                        void* y, int n, int h, int w, int ci, int k, int dtype, hipStream_t s);
+
+long conv_to3_absorb_norm_ws_elems(int n, int ci, int k, int dtype) {
+    if (dtype != STMI_BF16 || k != 9 || ci != 32 || !conv_to3_supported(k, ci, dtype)) return 0;
+    return ((long)n * ci + 7) / 8 * 8 + (long)n * k * 32 * ci + 2 * (long)n * 32;
+}
+
+int conv_to3_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
+                              float eps, float* in_stats, const void* wq, void* y, void* ws, int n, int h, int w, int ci, int k,
+                              int dtype, hipStream_t s) {
+    STMI_REQUIRE(conv_to3_absorb_norm_ws_elems(n, ci, k, dtype) > 0,
+                 "conv_to3 absorb norm: this geometry is not supported (stmi_conv2d_to3_absorb_norm_ws_bytes returned 0)");
+    const long welems = (long)k * 32 * ci;
+    const size_t es = 2;
+    void* clamp_t = ws;
+    char* wps = static_cast<char*>(ws) + (((long)n * ci + 7) / 8 * 8) * es;
+    float* bias = reinterpret_cast<float*>(wps + (((long)n * welems * es + 15) / 16) * 16);
+    int rc = in_stats_from_tiles_impl(in_tiles, in_ts, in_stats, eps, n, ci, s);
+    if (rc) return rc;
+    rc = in_absorb_prep_impl(in_stats, in_scale, in_shift, wq, clamp_t, wps, bias, n, ci, ci, 32, k, 32, dtype, s);
+    if (rc) return rc;
+    return conv_to3_clamp_impl(x, wps, welems, clamp_t, bias, y, n, h, w, ci, k, dtype, s);
+}
+
 // Floats of workspace with which a forward (dgrad == 0) or stride-1 backward-data (dgrad != 0) convolution of this
 // geometry splits its K loop over several blocks per tile; 0: it never does.  Assumes 16-byte aligned tensors.
 long conv_ksplit_ws_floats(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, int dgrad) {

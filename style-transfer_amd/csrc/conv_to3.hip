@@ -26,9 +26,20 @@ constexpr int kTo3Stride = 33;  // floats per pixel of t in LDS: odd, so the fol
 
 // K: kernel size; RB: bytes of input channels per pixel (64 or 128); COLS = PW + K - 1 columns of t per
 // block (a multiple of 8, so that the 8 x COLS pixels are whole 16-pixel fragments for each of the 4 waves).
-template <typename T, int K, int RB, int COLS>
+// CLAMP (bf16): the launch absorbs the instance norm + ReLU in front of it (see ConvGemmParams::clamp_t): the patch
+// goes to LDS as max(x, t[n][ci]) -- t itself outside the image --, the weights are the sample's own scaled copy
+// (w_stride elements apart), and the fold starts from the constant terms of its (kx, co) rows (bias_rows [n][32]).
+struct To3Clamp {
+    const void* t;          // [N][CI] of T
+    const float* bias_rows; // [N][32]
+    long w_stride;
+};
+
+template <typename T, int K, int RB, int COLS, bool CLAMP = false>
 __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, const T* __restrict__ wq,
-                                                       const T* __restrict__ addend, T* __restrict__ y, int N, int H, int W) {
+                                                       const T* __restrict__ addend, T* __restrict__ y, int N, int H, int W,
+                                                       To3Clamp cl) {
+    static_assert(!CLAMP || sizeof(T) == 2, "the clamp compares bf16 bit patterns");
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int CI = RB / (int)sizeof(T);
     constexpr int CPR = RB / 16;               // 16-byte chunks per pixel row
@@ -62,15 +73,24 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, 
     const int ty0 = (t / tiles_x) * PH, tx0 = (t % tiles_x) * PW;
 
     // weights and patch -> LDS, 16 bytes per access, chunk p of row r at position p ^ swz(r)
+    const T* wn = CLAMP ? wq + (long)n * cl.w_stride : wq;
     for (int i = tid; i < K * 32 * CPR; i += 256) {
         const int row = i / CPR, pos = i - row * CPR;
         const int chunk = pos ^ to3_swz<RB>(row & 31);
-        *reinterpret_cast<uint4*>(wl + row * RB + pos * 16) = *reinterpret_cast<const uint4*>(wq + (long)row * CI + chunk * EPC);
+        *reinterpret_cast<uint4*>(wl + row * RB + pos * 16) = *reinterpret_cast<const uint4*>(wn + (long)row * CI + chunk * EPC);
     }
     {
         constexpr int TOTAL = P_PIX * CPR, ROUNDS = (TOTAL + 255) / 256;
         const T* img = x + (long)n * H * W * CI;
         uint4 v[ROUNDS];
+        // CLAMP: the clamp values of the two chunks this thread ever loads (position tid % CPR, swizzled or not)
+        static_assert(!CLAMP || (RB == 64 && 256 % CPR == 0), "one chunk position per thread, two swizzle states");
+        uint4 tq_plain = make_uint4(0u, 0u, 0u, 0u), tq_swz = tq_plain;
+        if constexpr (CLAMP) {
+            const T* t_n = (const T*)cl.t + (long)n * CI;
+            tq_plain = *reinterpret_cast<const uint4*>(t_n + (tid % CPR) * EPC);
+            tq_swz = *reinterpret_cast<const uint4*>(t_n + ((tid % CPR) ^ 2) * EPC);
+        }
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
             const int i = tid + j * 256;
@@ -78,12 +98,27 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, 
             const int r = pr / COLS, c = pr - r * COLS;
             const int iy = ty0 - PAD + r, ix = tx0 - PAD + c;
             v[j] = make_uint4(0u, 0u, 0u, 0u);
+            const int swz = to3_swz<RB>(pr);
+            const int chunk = pos ^ swz;
+            uint4 tq = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (CLAMP) {
+                tq = swz ? tq_swz : tq_plain;   // (a thread's chunk position is the same in every round)
+                v[j] = tq;   // outside the image: the value the absorbed norm maps to zero
+            }
             if (i < TOTAL && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v[j] = *reinterpret_cast<const uint4*>(img + ((long)iy * W + ix) * CI + (pos ^ to3_swz<RB>(pr)) * EPC);
+                v[j] = *reinterpret_cast<const uint4*>(img + ((long)iy * W + ix) * CI + chunk * EPC);
         }
+        // (the maxima come in a second loop: behind each load they would wait for it, one round trip per round)
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
             const int i = tid + j * 256;
+            if constexpr (CLAMP) {   // bf16 bit patterns order like fp16 ones: one packed maximum per register
+                const uint4 tq = to3_swz<RB>(i / CPR) ? tq_swz : tq_plain;
+                asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[j].x) : "v"(tq.x));
+                asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[j].y) : "v"(tq.y));
+                asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[j].z) : "v"(tq.z));
+                asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[j].w) : "v"(tq.w));
+            }
             if (i < TOTAL) *reinterpret_cast<uint4*>(pl + i * 16) = v[j];
         }
     }
@@ -139,7 +174,10 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int kx = 0; kx < K; kx++) {
 #pragma unroll
-            for (int co = 0; co < 3; co++) s[co] += row[kx * kTo3Stride + kx * 3 + co];
+            for (int co = 0; co < 3; co++) {
+                s[co] += row[kx * kTo3Stride + kx * 3 + co];
+                if constexpr (CLAMP) s[co] += cl.bias_rows[n * 32 + kx * 3 + co];
+            }
         }
         const long e = (((long)n * H + oy) * W + ox) * 3;
 #pragma unroll
@@ -154,25 +192,26 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(const T* __restrict__ x, 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename T, int K, int RB, int COLS>
-static int launch_to3(const void* x, const void* wq, const void* addend, void* y, int n, int h, int w, hipStream_t s) {
+template <typename T, int K, int RB, int COLS, bool CLAMP = false>
+static int launch_to3(const void* x, const void* wq, const void* addend, void* y, int n, int h, int w, hipStream_t s,
+                      To3Clamp cl = To3Clamp{nullptr, nullptr, 0}) {
     constexpr int PW = COLS - (K - 1);
     constexpr int OPS = K * 32 * RB + (kTo3PH + K - 1) * COLS * RB;
     constexpr int TBYTES = kTo3PH * COLS * kTo3Stride * 4;
     constexpr size_t kLds = (size_t)((OPS > TBYTES ? OPS : TBYTES) + 15) / 16 * 16;
-    STMI_DYN_LDS((conv_to3_kernel<T, K, RB, COLS>), (int)kLds, "hipFuncSetAttribute(conv_to3_kernel)");
+    STMI_DYN_LDS((conv_to3_kernel<T, K, RB, COLS, CLAMP>), (int)kLds, "hipFuncSetAttribute(conv_to3_kernel)");
     {
         char name[160];
         const char* tn = sizeof(T) == 2 ? "__bf16" : "float";
-        snprintf(name, sizeof(name), "void stmi::conv_to3_kernel<%s, %d, %d, %d>(%s const*, %s const*, %s const*, %s*, int, int, int)",
-                 tn, K, RB, COLS, tn, tn, tn, tn);
+        snprintf(name, sizeof(name), "void stmi::conv_to3_kernel<%s, %d, %d, %d, %s>(%s const*, %s const*, %s const*, %s*, int, int, int, stmi::To3Clamp)",
+                 tn, K, RB, COLS, CLAMP ? "true" : "false", tn, tn, tn, tn);
         set_last_conv_kernel(name);
     }
     const long tiles = (long)n * ceil_div(h, kTo3PH) * ceil_div(w, PW);
     if (tiles <= 0) return STMI_OK;
     STMI_REQUIRE(tiles < (1L << 31), "conv_to3: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_to3_kernel<T, K, RB, COLS>), dim3((unsigned)tiles), dim3(256), kLds, s, (const T*)x, (const T*)wq,
-                       (const T*)addend, (T*)y, n, h, w);
+    hipLaunchKernelGGL((conv_to3_kernel<T, K, RB, COLS, CLAMP>), dim3((unsigned)tiles), dim3(256), kLds, s, (const T*)x, (const T*)wq,
+                       (const T*)addend, (T*)y, n, h, w, cl);
     STMI_LAUNCH_CHECK("conv_to3_kernel");
     return STMI_OK;
 }
@@ -193,6 +232,15 @@ int conv_to3_impl(const void* x, const void* wq, const void* addend, void* y, in
     }
     if (ci == 64) return launch_to3<bf16_t, 3, 128, 32>(x, wq, addend, y, n, h, w, s);  // fp32 rows would be 256 bytes
     return bf ? launch_to3<bf16_t, 3, 64, 32>(x, wq, addend, y, n, h, w, s) : launch_to3<float, 3, 128, 32>(x, wq, addend, y, n, h, w, s);
+}
+
+// The 9 x 9 layer absorbing the norm + ReLU in front of it (bf16, 32 input channels): see To3Clamp.
+int conv_to3_clamp_impl(const void* x, const void* wq_samples, long w_stride, const void* clamp_t, const float* bias_rows,
+                        void* y, int n, int h, int w, int ci, int k, int dtype, hipStream_t s) {
+    STMI_REQUIRE(dtype == STMI_BF16 && k == 9 && ci == 32, "conv_to3 (absorbing a norm): bf16, 9 x 9, 32 input channels only");
+    STMI_REQUIRE((((uintptr_t)x | (uintptr_t)wq_samples | (uintptr_t)clamp_t) & 15) == 0 && w_stride % 8 == 0,
+                 "conv_to3: x, the weights and the clamp values must be 16-byte aligned");
+    return launch_to3<bf16_t, 9, 64, 40, true>(x, wq_samples, nullptr, y, n, h, w, s, To3Clamp{clamp_t, bias_rows, w_stride});
 }
 
 }  // namespace stmi

@@ -247,14 +247,19 @@ class StylizerNet:
             nb = self.blocks[i + 1]
             # the next block must read the tensor for its convolution only (a residual block's first convolution
             # also keeps it as the skip tensor), and leave tile sums for its own norm
-            if nb.role == 'a' or b.tile_stats is None or nb.tile_stats is None or b.act != ops.ACT_RELU:
-                continue
-            if nb.kind != 'conv' or nb.rows is not None or nb.k != 3:
+            if nb.role == 'a' or b.tile_stats is None or b.act != ops.ACT_RELU:
                 continue
             shape = (self.n, b.out_h, b.out_w, b.co)
-            need = ops.conv_absorb_norm_ws_bytes(shape, nb.kshape, nb.s, self.dtype)
-            if need == 0 or ops.conv_absorb_norm_tiles(shape, nb.kshape, nb.s, self.dtype) != nb.tile_stats.shape[1]:
-                continue
+            if nb.kind == 'conv' and nb.rows == 'out' and nb.to3:      # the 9 x 9 layer into three channels
+                need = ops.conv_to3_absorb_norm_ws_bytes(shape, nb.k, self.dtype)
+                if need == 0:
+                    continue
+            else:
+                if nb.kind != 'conv' or nb.rows is not None or nb.k != 3 or nb.tile_stats is None:
+                    continue
+                need = ops.conv_absorb_norm_ws_bytes(shape, nb.kshape, nb.s, self.dtype)
+                if need == 0 or ops.conv_absorb_norm_tiles(shape, nb.kshape, nb.s, self.dtype) != nb.tile_stats.shape[1]:
+                    continue
             if bool((b.scale > 0).all()):
                 if self._absorb_ws is None or self._absorb_ws.numel() < need:
                     self._absorb_ws = torch.empty(need, dtype=torch.uint8, device=b.scale.device)
@@ -324,6 +329,10 @@ class StylizerNet:
             elif b.rows == 'in':
                 ops.pixels_to_rows(cur, b.k, -b.pad_left, out=b.rows_buf)
                 ops.conv2d_fwd(b.rows_buf, b.wp_fwd, (b.k, 1, 32, b.co), 1, out=conv_out)
+            elif b.rows == 'out' and b.to3 and absorbed is not None:
+                ops.conv2d_to3_absorb_norm(cur, absorbed.tile_stats, absorbed.scale, absorbed.shift, b.wp_fwd, b.k,
+                                           absorbed.absorb_ws, in_stats=absorbed.stats, out=conv_out)
+                absorbed = None
             elif b.rows == 'out' and b.to3:
                 ops.conv2d_to3(cur, b.wp_fwd, b.k, out=conv_out)
             elif b.rows == 'out':

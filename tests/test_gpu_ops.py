@@ -233,6 +233,38 @@ def test_stride2_convolution_absorbing_the_norm_in_front_of_it(cuda, case):
     assert rel_err(out, ref) <= TOL[dtype]
 
 
+@pytest.mark.parametrize('case', [(2, 24, 64), (1, 37, 45)], ids=lambda c: 'x'.join(map(str, c)))
+def test_output_layer_absorbing_the_norm_in_front_of_it(cuda, case):
+    """full_graph_stylizer_network.py:76-78 at inference: the 9 x 9 layer into three channels reading the raw output
+    of the last up-sampling block and applying that block's norm + ReLU on the way in."""
+    from stmi import ops
+    n, h, w = case
+    dtype, c, k = torch.bfloat16, 32, 9
+    xa64 = rnd((n, h, w, c), 1) * 0.8 + 0.3
+    wb = rnd((k, k, c, 3), 3, 1.0 / np.sqrt(k * k * c))
+    sa, ha = rnd((c,), 4).abs() + 0.5, rnd((c,), 5)
+    xa = xa64.to(cuda, dtype)
+    wpb = ops.pack_conv_weights(wb.to(cuda, torch.float32), ops.PACK_FWD_ROWOUT, dtype)
+    sad, had = sa.to(cuda, torch.float32), ha.to(cuda, torch.float32)
+    need = ops.conv_to3_absorb_norm_ws_bytes((n, h, w, c), k, dtype)
+    assert need > 0 and ops.conv_to3_absorb_norm_ws_bytes((n, h, w, c), k, torch.float32) == 0
+    xf = xa.float()
+    k0 = xf[:, 0, 0, :]
+    d = xf - k0[:, None, None, :]
+    tiles_a = torch.stack([k0, d.sum(dim=(1, 2)), (d * d).sum(dim=(1, 2)), torch.full_like(k0, float(h * w))], dim=1)[:, None].contiguous()
+    ya, st_ref = ops.instance_norm_fwd(xa, sad, had, ops.ACT_RELU)
+    zr = ops.conv2d_to3(ya, wpb, k)
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    z, st = ops.conv2d_to3_absorb_norm(xa, tiles_a, sad, had, wpb, k, ws)
+    assert 'conv_to3_kernel<__bf16, 9, 64, 40, true>' in ops.last_conv_kernel()
+    assert rel_err(st[..., 1], st_ref[..., 1].double()) <= 1e-4
+    assert rel_err(z, zr.double()) <= 3e-2
+    y64 = torch.relu(O.instance_norm(q(xa64, dtype), sa.float().double(), ha.float().double()))
+    ref = O.conv2d_same(y64, q(wb, dtype), 1)
+    assert rel_err(z, ref) <= TOL[dtype]
+    assert rel_err(zr, ref) <= TOL[dtype]
+
+
 KSPLIT_CASES = [
     # n, h, w, ci, co, forced slices (None: the planner's own choice, which must be a split)
     (4, 16, 16, 512, 512, None),     # VGG conv5_x of a training batch
