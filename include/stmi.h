@@ -259,6 +259,18 @@ int stmi_conv2d_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, 
 int stmi_conv2d_transpose_nhwc_fwd_tile_stats(const void* x, const void* w_packed_dgrad, void* y, float* tile_stats,
                                               int n, int h, int w, int ci, int co, int kh, int kw, int stride,
                                               int dtype, void* stream);
+
+/* stmi_conv2d_transpose_nhwc_fwd_tile_stats absorbing the instance norm + ReLU in front of it, as
+ * stmi_conv2d_nhwc_fwd_absorb_norm does for the forward layers (full_graph_stylizer_network.py:72-76: the first
+ * up-sampling block's norm and the second block's transposed convolution): x is the raw output of the layer in
+ * front, in_tile_stats the tile sums it left.  bf16, 3x3 stride 2, 64 input channels.
+ * stmi_conv2d_transpose_absorb_norm_ws_bytes: bytes of the 16-byte aligned workspace, 0: not supported. */
+long stmi_conv2d_transpose_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int stmi_conv2d_transpose_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles,
+                                               const float* in_scale, const float* in_shift, float eps, float* in_stats,
+                                               const void* w_packed_dgrad, void* y, float* tile_stats, void* ws,
+                                               int n, int h, int w, int ci, int co, int kh, int kw, int stride,
+                                               int dtype, void* stream);
 /* dy [n,s*h,s*w,co] -> dx [n,h,w,ci]; W packed with STMI_PACK_FWD, (ci_pack, co_pack) = (co, ci). */
 int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx,
                                      const void* addend,

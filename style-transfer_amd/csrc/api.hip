@@ -48,7 +48,12 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
                     const InBwdSums* bn = nullptr, float* tile_stats = nullptr, int tile_stats_ts = 0,
-                    float* ws = nullptr, long ws_floats = 0);
+                    float* ws = nullptr, long ws_floats = 0, const AbsorbClamp* cl = nullptr);
+long conv_transpose_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
+int conv_transpose_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale,
+                                        const float* in_shift, float eps, float* in_stats, const void* wp, void* y,
+                                        float* tile_stats, void* ws, int n, int h, int w, int ci, int co, int kh, int kw,
+                                        int stride, int dtype, hipStream_t s);
 long conv_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_absorb_norm_tiles(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype);
 int conv_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale, const float* in_shift,
@@ -427,6 +432,25 @@ int stmi_conv2d_transpose_nhwc_fwd_tile_stats(const void* x, const void* w_packe
                  "(stmi_conv2d_transpose_tile_stats_tiles returned 0)");
     return conv_dgrad_impl(x, w_packed_dgrad, y, nullptr, nullptr, 1.f, n, h * stride, w * stride, co, ci, kh, kw, stride,
                            dtype, S(stream), nullptr, tile_stats, ts);
+}
+
+long stmi_conv2d_transpose_absorb_norm_ws_bytes(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (n <= 0 || h <= 0 || w <= 0 || ci <= 0 || co <= 0 || kh <= 0 || kw <= 0 || (dtype != STMI_F32 && dtype != STMI_BF16)) return 0;
+    const long elems = conv_transpose_absorb_norm_ws_elems(n, h, w, ci, co, kh, kw, stride, dtype);
+    return elems > 0 ? elems * 2 + 32 : 0;
+}
+
+int stmi_conv2d_transpose_nhwc_fwd_absorb_norm(const void* x, const float* in_tile_stats, int in_tiles, const float* in_scale,
+                                               const float* in_shift, float eps, float* in_stats, const void* w_packed_dgrad,
+                                               void* y, float* tile_stats, void* ws, int n, int h, int w, int ci, int co,
+                                               int kh, int kw, int stride, int dtype, void* stream) {
+    if (check_conv("conv2d_transpose_nhwc_fwd_absorb_norm", n, h, w, ci, co, kh, kw, stride, dtype)) return STMI_ERR_INVALID;
+    if (n == 0) return STMI_OK;  // an empty batch has no buffers
+    STMI_REQUIRE(x && in_tile_stats && in_scale && in_shift && in_stats && w_packed_dgrad && y && tile_stats && ws,
+                 "conv2d_transpose_nhwc_fwd_absorb_norm: null pointer");
+    STMI_REQUIRE(in_tiles > 0 && (((uintptr_t)ws) & 15) == 0, "conv2d_transpose_nhwc_fwd_absorb_norm: bad tile count or unaligned workspace");
+    return conv_transpose_fwd_absorb_norm_impl(x, in_tile_stats, in_tiles, in_scale, in_shift, eps, in_stats, w_packed_dgrad, y,
+                                               tile_stats, ws, n, h, w, ci, co, kh, kw, stride, dtype, S(stream));
 }
 
 int stmi_conv2d_transpose_nhwc_dgrad(const void* dy, const void* w_packed_fwd, void* dx, const void* addend, int n,

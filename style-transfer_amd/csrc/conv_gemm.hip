@@ -488,7 +488,7 @@ int conv_fwd_impl(const void* x, const void* wp, const float* bias, void* y, voi
 int in_stats_from_tiles_impl(const float* tiles, int ts, float* stats, float eps, int n, int c, hipStream_t s);   // instnorm.hip
 int in_absorb_prep_impl(const float* stats, const float* scale, const float* shift, const void* wp, void* clamp_t,
                         void* wps, float* bias, int n, int c, int kpad, int rows_pad, int taps, int co, int dtype,
-                        hipStream_t s);
+                        hipStream_t s, const signed char* tap_groups = nullptr, int groups = 1);
 
 // 3x3 convolution (stride 1 or 2) of relu(IN(x)) given x, the tile sums of x (from the convolution that wrote it)
 // and the norm's scale (> 0) / shift -- without the normalised tensor ever being written: see
@@ -680,8 +680,10 @@ static bool build_multi_class(const ConvGemmParams& p, int h, int w, int kh, int
 // convolution also leaves the per-tile sums of dx for the instance norm behind it.
 int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, const void* addend, float alpha,
                     int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype, hipStream_t s,
-                    const InBwdSums* bn, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats) {
+                    const InBwdSums* bn, float* tile_stats, int tile_stats_ts, float* ws, long ws_floats,
+                    const AbsorbClamp* cl) {
     int ho, wo, pt, pl;
+    STMI_REQUIRE(!cl || (stride == 2 && tile_stats && !bn), "conv dgrad: a norm is absorbed by the up-sampling kernel only");
     same_pads(h, kh, stride, &ho, &pt);
     same_pads(w, kw, stride, &wo, &pl);
     const PackGeom g = pack_geom(kh, kw, ci, co, STMI_PACK_DGRAD);
@@ -723,7 +725,11 @@ int conv_dgrad_impl(const void* dy, const void* wp, void* dx, const void* mask, 
             if (tile_stats) {
                 m.tile_stats = tile_stats; m.tile_stats_ts = tile_stats_ts; m.tile_stats_mode = 1;
             }
+            if (cl) {
+                m.clamp_t = cl->t; m.clamp_bias = cl->bias; m.w_batch_stride = cl->w_stride;
+            }
             if (try_launch_conv_up2(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
+            STMI_REQUIRE(!cl, "transposed conv: this geometry cannot absorb a norm");
             STMI_REQUIRE(!tile_stats, "transposed conv: this geometry leaves no tile statistics");
             if (try_launch_conv_gemm_pc_multi(m, dtype, s, &rc, g_last_conv_kernel, (int)sizeof(g_last_conv_kernel))) return rc;
         }
@@ -783,6 +789,56 @@ int conv_transpose_tile_stats_tiles(int n, int h, int w, int ci, int co, int kh,
     ConvGemmParams m;
     if (!build_multi_class(p, H, W, kh, kw, stride, pt, pl, dtype, m)) return 0;
     return conv_up2_tile_stats_tiles(m, dtype);
+}
+
+// The forward of a transposed 3x3 stride-2 convolution x[n,h,w,ci] -> y[n,2h,2w,co] absorbing the norm + ReLU in front
+// of it (up-sampling kernel, bf16, 64 input channels).  ws: n * ci clamp values, n packed-weight copies, n * 9 * co
+// floats of constant terms by output class (the four classes use different taps).
+long conv_transpose_absorb_norm_ws_elems(int n, int h, int w, int ci, int co, int kh, int kw, int stride, int dtype) {
+    if (dtype != STMI_BF16 || kh != 3 || kw != 3 || stride != 2 || ci * 2 != 128) return 0;
+    if (conv_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype) <= 0) return 0;
+    const PackGeom g = pack_geom(kh, kw, co, ci, STMI_PACK_DGRAD);
+    return ((long)n * ci + 7) / 8 * 8 + (long)n * g.ntaps * g.rows_pad * g.kpad + 2 * (long)n * 4 * co;
+}
+
+int conv_transpose_fwd_absorb_norm_impl(const void* x, const float* in_tiles, int in_ts, const float* in_scale,
+                                        const float* in_shift, float eps, float* in_stats, const void* wp, void* y,
+                                        float* tile_stats, void* ws, int n, int h, int w, int ci, int co, int kh, int kw,
+                                        int stride, int dtype, hipStream_t s) {
+    STMI_REQUIRE(conv_transpose_absorb_norm_ws_elems(n, h, w, ci, co, kh, kw, stride, dtype) > 0,
+                 "transposed conv absorb norm: this geometry is not supported (stmi_conv2d_transpose_absorb_norm_ws_bytes returned 0)");
+    const PackGeom g = pack_geom(kh, kw, co, ci, STMI_PACK_DGRAD);
+    const long welems = (long)g.ntaps * g.rows_pad * g.kpad;
+    const size_t es = 2;
+    void* clamp_t = ws;
+    char* wps = static_cast<char*>(ws) + (((long)n * ci + 7) / 8 * 8) * es;
+    float* bias = reinterpret_cast<float*>(wps + (((long)n * welems * es + 15) / 16) * 16);
+    int rc = in_stats_from_tiles_impl(in_tiles, in_ts, in_stats, eps, n, ci, s);
+    if (rc) return rc;
+    // class slot (2 (oy & 1) + (ox & 1), as the kernel numbers its accumulators) of every tap of the 3 x 3 kernel
+    signed char slot_of[32];
+    for (int i = 0; i < 32; i++) slot_of[i] = -1;
+    {
+        const int H = h * stride, W = w * stride;
+        int ho, wo, pt, pl;
+        same_pads(H, kh, stride, &ho, &pt);
+        same_pads(W, kw, stride, &wo, &pl);
+        ConvGemmParams p, m;
+        clear_params(p);
+        p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = ci; p.Ho = H; p.Wo = W; p.Co = co;
+        p.klen = g.klen; p.kpad = g.kpad; p.co_pad = g.rows_pad; p.in_stride = 1;
+        STMI_REQUIRE(build_multi_class(p, H, W, kh, kw, stride, pt, pl, dtype, m), "transposed conv absorb norm: no class table");
+        for (int c = 0; c < m.nclasses; c++)
+            for (int t = m.cls[c].tap0; t < m.cls[c].tap0 + m.cls[c].ntaps; t++)
+                slot_of[m.taps[t].widx] = (signed char)(2 * m.cls[c].oy0 + m.cls[c].ox0);
+    }
+    rc = in_absorb_prep_impl(in_stats, in_scale, in_shift, wp, clamp_t, wps, bias, n, ci, g.kpad, g.rows_pad, g.ntaps, co, dtype, s,
+                             slot_of, 4);
+    if (rc) return rc;
+    const AbsorbClamp cl{clamp_t, bias, welems};
+    const int ts = conv_transpose_tile_stats_tiles(n, h, w, ci, co, kh, kw, stride, dtype);
+    return conv_dgrad_impl(x, wps, y, nullptr, nullptr, 1.f, n, h * stride, w * stride, co, ci, kh, kw, stride, dtype, s, nullptr,
+                           tile_stats, ts, nullptr, 0, &cl);
 }
 
 int gram_bwd_impl(const void* f, const void* sp, void* df, int accumulate, int n, int h, int w, int c, int dtype,

@@ -552,6 +552,14 @@ struct InBwdSums {
     int act;
 };
 
+// Optional extra of a launch that absorbs the instance norm + ReLU in front of it (ConvGemmParams::clamp_t,
+// clamp_bias, w_batch_stride).
+struct AbsorbClamp {
+    const void* t;
+    const float* bias;
+    long w_stride;
+};
+
 // Name (as a profiler prints it) of the conv kernel launched last by this thread.
 void set_last_conv_kernel(const char* name);
 

@@ -58,8 +58,13 @@ constexpr int kPatchPieces = (kMaxPatchRows + 31) / 32;   // 8-row pieces per wa
 // rows: in bf16 with two small MFMAs per fragment (ones^T Y and the diagonal of Y^T Y; plain sums are exact
 // enough for a tensor that itself has eight bits of mantissa, and each wave moves them to a shift before
 // they leave), in fp32 as shifted sums in the lanes that store the rows.
-template <typename T, int NCH, int COF, bool STATS>
-__global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
+// CLAMP (bf16, one chunk per pixel): ConvGemmParams::clamp_t -- the launch absorbs the instance norm + ReLU in front
+// of it: fragments are clamped from below by the sample's t values, rows outside the image hold t, the weights are
+// the sample's own scaled copy, and every output class starts from the constant terms of ITS taps
+// (clamp_bias [n][4][Co], by class slot 2 (oy & 1) + (ox & 1)).
+template <typename T, int NCH, int COF, bool STATS, bool CLAMP>
+__device__ __forceinline__ void conv_up2_body(const ConvGemmParams& p) {
+    static_assert(!CLAMP || (sizeof(T) == 2 && NCH == 1), "the clamp is for bf16 pixels of one 128-byte chunk");
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 8 * EPC;                    // channels per chunk
     constexpr int CO = 16 * COF;
@@ -98,6 +103,8 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     {
         const T* in = (const T*)p.in;
         const T* zero_src = (const T*)(g_up2_zero_page + pos);
+        // CLAMP: outside the image the sample's clamp values (this lane's piece of the chunk: pr & 7 == sub)
+        const T* t_src = CLAMP ? (const T*)p.clamp_t + (long)n * C + (pos ^ sub) * EPC : nullptr;
 #pragma unroll
         for (int i = 0; i < kPatchPieces; i++) {
             const int pr = (wave * kPatchPieces + i) * 8 + sub;
@@ -107,11 +114,11 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
             const T* src = in + ((long)(n * H + iy) * W + ix) * C + (pos ^ (pr & 7)) * EPC;
 #pragma unroll
             for (int c = 0; c < NCH; c++)
-                glds16(ok ? src + c * BK : zero_src, patch_base + c * P_CHUNK + (wave * kPatchPieces + i) * 1024);
+                glds16(ok ? src + c * BK : (CLAMP ? t_src + c * BK : zero_src), patch_base + c * P_CHUNK + (wave * kPatchPieces + i) * 1024);
         }
     }
     // weight tile of step s = (tap index in the table, chunk): rows CO x 128 bytes, swizzled like the consumers read
-    const T* wp = (const T*)p.wp;
+    const T* wp = (const T*)p.wp + (CLAMP ? (long)n * p.w_batch_stride : 0L);
     int wrow_off[NI_W];
 #pragma unroll
     for (int j = 0; j < NI_W; j++) {
@@ -131,15 +138,28 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     if (nsteps > 1) stage_weights(1);
 
     // ---------------------------------------------------------------- K loop
+    const int g = lane >> 4, r16 = lane & 15;
     f32x4 acc[4][COF][2];
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int a = 0; a < COF; a++)
+        for (int a = 0; a < COF; a++) {
+            f32x4 start = {0.f, 0.f, 0.f, 0.f};
+            // CLAMP: a class starts from the constant terms of its own taps (C/D rows 4 g + u of channel fragment a)
+            if constexpr (CLAMP) start = *reinterpret_cast<const f32x4*>(p.clamp_bias + ((long)n * 4 + c) * p.Co + a * 16 + 4 * g);
 #pragma unroll
-            for (int b = 0; b < 2; b++) acc[c][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 2; b++) acc[c][a][b] = start;
+        }
+    // CLAMP: the eight clamp values of this lane's fragment registers, per 64-byte half of the chunk
+    u32x4 tv[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
+    if constexpr (CLAMP) {
+        const T* t_n = (const T*)p.clamp_t + (long)n * C;
+        const uint4 t0 = *reinterpret_cast<const uint4*>(t_n + 8 * g);
+        const uint4 t1 = *reinterpret_cast<const uint4*>(t_n + 32 + 8 * g);
+        tv[0] = (u32x4){t0.x, t0.y, t0.z, t0.w};
+        tv[1] = (u32x4){t1.x, t1.y, t1.z, t1.w};
+    }
 
-    const int g = lane >> 4, r16 = lane & 15;
     const unsigned a_off = lds_base + r16 * 128 + ((g ^ ((r16 >> 1) & 7)) << 4);
     // patch row of this lane's two pixel columns under a tap with offset (0, 0)
     const int pr0 = (wave - dy_min) * PWH + r16 - dx_min;
@@ -178,6 +198,18 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
                     for (int k = 0; k < COF; k++) lds_landed(fa[h][k]);
 #pragma unroll
                     for (int f = 0; f < 2; f++) lds_landed(fb[h][f]);
+                }
+                if constexpr (CLAMP) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int f = 0; f < 2; f++)
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                unsigned r;
+                                asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(fb[h][f][u]), "v"(tv[h][u]));
+                                fb[h][f][u] = r;
+                            }
                 }
 #pragma unroll
                 for (int h = 0; h < 2; h++)
@@ -283,16 +315,33 @@ __global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
     }
 }
 
+template <typename T, int NCH, int COF, bool STATS, bool CLAMP = false>
+__global__ __launch_bounds__(256) void conv_up2_kernel(const ConvGemmParams p) {
+    conv_up2_body<T, NCH, COF, STATS, CLAMP>(p);
+}
+
+// The absorbing form is bound by its stores like the plain one and wants the same four blocks per CU: the clamp
+// values and pointers would otherwise push it over 128 registers.
+template <typename T, int NCH, int COF>
+__global__ __launch_bounds__(256, 4) void conv_up2_clamp_kernel(const ConvGemmParams p) {
+    conv_up2_body<T, NCH, COF, true, true>(p);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename T, int NCH, int COF, bool STATS>
+template <typename T, int NCH, int COF, bool STATS, bool CLAMP = false>
 static int launch_up2(const ConvGemmParams& p, hipStream_t s) {
     constexpr size_t kOperands = (size_t)kRing * 16 * COF * 128 + (size_t)NCH * 4 * kPatchPieces * 1024;
     constexpr size_t kStage = (size_t)4 * 64 * (16 * COF * sizeof(T) + 16);
     constexpr size_t kLds = kOperands > kStage ? kOperands : kStage;
-    STMI_DYN_LDS((conv_up2_kernel<T, NCH, COF, STATS>), (int)kLds, "hipFuncSetAttribute(conv_up2_kernel)");
-    hipLaunchKernelGGL((conv_up2_kernel<T, NCH, COF, STATS>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
+    if constexpr (CLAMP) {
+        STMI_DYN_LDS((conv_up2_clamp_kernel<T, NCH, COF>), (int)kLds, "hipFuncSetAttribute(conv_up2_clamp_kernel)");
+        hipLaunchKernelGGL((conv_up2_clamp_kernel<T, NCH, COF>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
+    } else {
+        STMI_DYN_LDS((conv_up2_kernel<T, NCH, COF, STATS, CLAMP>), (int)kLds, "hipFuncSetAttribute(conv_up2_kernel)");
+        hipLaunchKernelGGL((conv_up2_kernel<T, NCH, COF, STATS, CLAMP>), dim3(p.pt_div[1] * p.pt_div[2] * (unsigned)p.N), dim3(256), kLds, s, p);
+    }
     STMI_LAUNCH_CHECK("conv_up2_kernel");
     return STMI_OK;
 }
@@ -311,7 +360,11 @@ static bool up2_prepare(const ConvGemmParams& p, int dtype, ConvGemmParams& q) {
     if (p.klen != p.Ci || (p.Ci * es) % 128 != 0 || (p.Co != 32 && p.Co != 64) || p.co_pad < p.Co) return false;
     const int nch = p.Ci * es / 128;
     if (nch != 1 && nch != 2 && nch != 4) return false;
-    if (p.bias || p.mask || p.addend || p.out_pre || p.relu || p.w_batch_stride != 0) return false;
+    if (p.bias || p.mask || p.addend || p.out_pre || p.relu || (p.w_batch_stride != 0 && !p.clamp_t)) return false;
+    // the absorbed-norm form: bf16, pixels of one chunk, with the statistics the next norm wants
+    if (p.clamp_t && (dtype != STMI_BF16 || p.Ci * es != 128 || !p.tile_stats || p.tile_stats_mode != 1 || p.w_batch_stride <= 0 ||
+                      !p.clamp_bias || (((uintptr_t)p.clamp_t | (uintptr_t)p.clamp_bias) & 15) != 0))
+        return false;
     if (p.tile_stats && p.tile_stats_mode != 1) return false;
     if ((((uintptr_t)p.in | (uintptr_t)p.wp | (uintptr_t)p.out) & 15) != 0) return false;
     if ((long)p.N * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.N * p.Ho * p.Wo * p.Co >= (1L << 31)) return false;
@@ -355,8 +408,11 @@ static bool up2_prepare(const ConvGemmParams& p, int dtype, ConvGemmParams& q) {
 }
 
 // Statistics rows per sample this kernel leaves for the launch p (one per block), 0 when p is not its layer.
-int conv_up2_tile_stats_tiles(const ConvGemmParams& p, int dtype) {
+int conv_up2_tile_stats_tiles(const ConvGemmParams& p_in, int dtype) {
     ConvGemmParams q;
+    ConvGemmParams p = p_in;   // a question about the geometry only
+    p.clamp_t = nullptr;
+    p.w_batch_stride = 0;
     if (!up2_prepare(p, dtype, q)) return 0;
     return (int)(q.pt_div[1] * q.pt_div[2]);
 }
@@ -369,8 +425,13 @@ bool try_launch_conv_up2(const ConvGemmParams& p, int dtype, hipStream_t s, int*
     const int nch = p.Ci * es / 128;
     const int cof = p.Co / 16;
     if (name)
-        snprintf(name, name_len, "void stmi::conv_up2_kernel<%s, %d, %d, %s>(stmi::ConvGemmParams)",
+        snprintf(name, name_len, p.clamp_t ? "void stmi::conv_up2_clamp_kernel<%s, %d, %d>(stmi::ConvGemmParams)"
+                                           : "void stmi::conv_up2_kernel<%s, %d, %d, %s, false>(stmi::ConvGemmParams)",
                  dtype == STMI_BF16 ? "__bf16" : "float", nch, cof, p.tile_stats ? "true" : "false");
+    if (p.clamp_t) {
+        *rc = cof == 2 ? launch_up2<bf16_t, 1, 2, true, true>(q, s) : launch_up2<bf16_t, 1, 4, true, true>(q, s);
+        return true;
+    }
     if (dtype == STMI_BF16) {
         if (nch == 1) *rc = cof == 2 ? launch_up2_s<bf16_t, 1, 2>(q, s) : launch_up2_s<bf16_t, 1, 4>(q, s);
         else if (nch == 2) *rc = cof == 2 ? launch_up2_s<bf16_t, 2, 2>(q, s) : launch_up2_s<bf16_t, 2, 4>(q, s);

@@ -925,38 +925,56 @@ __global__ __launch_bounds__(256) void in_absorb_prep_kernel(const float* __rest
     }
 }
 
+// groups: the taps' constant terms are summed by group (a transposed convolution's output classes use different
+// taps): bias is [n][groups][co] with tap `tap` adding to group group_of[tap] (< 0: to none); groups == 1: [n][co].
+struct TapGroups {
+    int groups;
+    signed char group_of[32];
+};
+
 template <typename T>
 __global__ __launch_bounds__(64) void in_absorb_bias_kernel(const T* __restrict__ clamp_t, const T* __restrict__ wps,
                                                             float* __restrict__ bias, int C, int kpad, int rows_pad, int taps,
-                                                            int co) {
+                                                            int co, TapGroups tg) {
     const int o = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
     const T* w_n = wps + (long)n * taps * rows_pad * kpad;
     const T* t_n = clamp_t + (long)n * C;
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tap = 0; tap < taps; tap++) {
         const T* row = w_n + ((long)tap * rows_pad + o) * kpad;
-        for (int k = lane; k < C; k += 64) acc += to_f32<T>(row[k]) * to_f32<T>(t_n[k]);
+        float a = 0.f;
+        for (int k = lane; k < C; k += 64) a += to_f32<T>(row[k]) * to_f32<T>(t_n[k]);
+        const int gi = tg.groups == 1 ? 0 : tg.group_of[tap];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] += gi == j ? a : 0.f;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) bias[(long)n * co + o] = -acc;
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off);
+        if (lane == 0 && j < tg.groups) bias[((long)n * tg.groups + j) * co + o] = -acc[j];
+    }
 }
 
 int in_absorb_prep_impl(const float* stats, const float* scale, const float* shift, const void* wp, void* clamp_t,
                         void* wps, float* bias, int n, int c, int kpad, int rows_pad, int taps, int co, int dtype,
-                        hipStream_t s) {
+                        hipStream_t s, const signed char* tap_groups, int groups) {
+    TapGroups tg;
+    tg.groups = groups > 1 ? groups : 1;
+    for (int i = 0; i < 32; i++) tg.group_of[i] = tap_groups && groups > 1 && i < taps ? tap_groups[i] : (signed char)0;
+    STMI_REQUIRE(taps <= 32 && tg.groups <= 4, "absorb prep: at most 32 taps in 4 groups");
     const long welems = (long)taps * rows_pad * kpad;
     const int bx = (int)((welems + 1023) / 1024 > 256 ? 256 : (welems + 1023) / 1024 > 0 ? (welems + 1023) / 1024 : 1);
     if (dtype == STMI_BF16) {
         hipLaunchKernelGGL(in_absorb_prep_kernel<bf16_t>, dim3(bx, n), dim3(256), 0, s, stats, scale, shift, (const bf16_t*)wp,
                            (bf16_t*)clamp_t, (bf16_t*)wps, c, kpad, welems);
         hipLaunchKernelGGL(in_absorb_bias_kernel<bf16_t>, dim3(co, n), dim3(64), 0, s, (const bf16_t*)clamp_t, (const bf16_t*)wps,
-                           bias, c, kpad, rows_pad, taps, co);
+                           bias, c, kpad, rows_pad, taps, co, tg);
     } else {
         hipLaunchKernelGGL(in_absorb_prep_kernel<float>, dim3(bx, n), dim3(256), 0, s, stats, scale, shift, (const float*)wp,
                            (float*)clamp_t, (float*)wps, c, kpad, welems);
         hipLaunchKernelGGL(in_absorb_bias_kernel<float>, dim3(co, n), dim3(64), 0, s, (const float*)clamp_t, (const float*)wps,
-                           bias, c, kpad, rows_pad, taps, co);
+                           bias, c, kpad, rows_pad, taps, co, tg);
     }
     STMI_LAUNCH_CHECK("in_absorb_prep kernels");
     return STMI_OK;

@@ -29,6 +29,8 @@ SIGNATURES = {
     'stmi_pack_conv_weights_multi': (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     'stmi_conv2d_nhwc_fwd': (_c_int, [_vp] * 5 + [_vp, _c_long] + _CONV + [_c_int, _c_int, _vp]),
     'stmi_conv2d_ksplit_ws_floats': (_c_long, _CONV + [_c_int, _c_int]),
+    'stmi_conv2d_transpose_absorb_norm_ws_bytes': (_c_long, _CONV + [_c_int]),
+    'stmi_conv2d_transpose_nhwc_fwd_absorb_norm': (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp] + _CONV + [_c_int, _vp]),
     'stmi_conv2d_to3_absorb_norm_ws_bytes': (_c_long, [_c_int] * 6),
     'stmi_conv2d_to3_nhwc_fwd_absorb_norm': (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_float, _vp, _vp, _vp, _vp] + [_c_int] * 6 + [_vp]),
     'stmi_conv2d_absorb_norm_ws_bytes': (_c_long, _CONV + [_c_int]),

@@ -297,6 +297,44 @@ def conv2d_rgb_u8_fwd(x_u8, w_packed, k, co, dtype, scale=1.0 / 255.0, mean=None
     return y
 
 
+def conv_transpose_absorb_norm_ws_bytes(x_shape, kshape, stride, dtype):
+    """Bytes of workspace conv2d_transpose_fwd_absorb_norm needs; 0: not supported."""
+    kh, kw, co, ci = kshape
+    n, h, w, _ = x_shape
+    return int(_lib.load().stmi_conv2d_transpose_absorb_norm_ws_bytes(n, h, w, ci, co, kh, kw, stride, _DT[dtype]))
+
+
+def conv2d_transpose_fwd_absorb_norm(x, in_tile_stats, in_scale, in_shift, w_packed, kshape, stride, tile_stats, ws,
+                                     in_stats=None, out=None, eps=None):
+    """conv2d_transpose_fwd(relu(IN(x))) with x the raw output of the layer in front (in_tile_stats: the tile sums it
+    left): the normalised tensor is never written.  Returns (y, in_stats); tile_stats receives the tile sums of y."""
+    kh, kw, co, ci = kshape
+    n, h, w, c = x.shape
+    assert c == ci, (c, ci)
+    _chk(x, 'x')
+    _chk(in_tile_stats, 'in_tile_stats', torch.float32)
+    assert in_tile_stats.dim() == 4 and in_tile_stats.shape[0] == n and in_tile_stats.shape[2:] == (4, ci), tuple(in_tile_stats.shape)
+    _chk(in_scale, 'in_scale', torch.float32, (ci,))
+    _chk(in_shift, 'in_shift', torch.float32, (ci,))
+    _chk(w_packed, 'w_packed', x.dtype, (packed_elems(kh, kw, co, ci, PACK_DGRAD),))
+    need = conv_transpose_absorb_norm_ws_bytes(x.shape, kshape, stride, x.dtype)
+    if need == 0:
+        raise ValueError('conv2d_transpose_fwd_absorb_norm: geometry not supported')
+    _chk(ws, 'ws', torch.uint8)
+    if ws.numel() < need:
+        raise ValueError('conv2d_transpose_fwd_absorb_norm: workspace of %d bytes, %d needed' % (ws.numel(), need))
+    ts = conv_transpose_tile_stats_tiles(x.shape, kshape, stride, x.dtype)
+    oshape = (n, h * stride, w * stride, co)
+    _chk(tile_stats, 'tile_stats', torch.float32, (n, ts, 4, co))
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device) if out is None else _chk(out, 'out', x.dtype, oshape)
+    st = torch.empty((n, ci, 2), dtype=torch.float32, device=x.device) if in_stats is None else _chk(in_stats, 'in_stats', torch.float32, (n, ci, 2))
+    _lib.call('stmi_conv2d_transpose_nhwc_fwd_absorb_norm', x.data_ptr(), in_tile_stats.data_ptr(), in_tile_stats.shape[1],
+              in_scale.data_ptr(), in_shift.data_ptr(), float(IN_EPS if eps is None else eps), st.data_ptr(),
+              w_packed.data_ptr(), y.data_ptr(), tile_stats.data_ptr(), ws.data_ptr(), n, h, w, ci, co, kh, kw, stride,
+              _dt(x), _stream())
+    return y, st
+
+
 def conv_to3_absorb_norm_ws_bytes(x_shape, k, dtype):
     """Bytes of workspace conv2d_to3_absorb_norm needs; 0: not supported."""
     n, h, w, ci = x_shape

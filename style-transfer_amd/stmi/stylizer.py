@@ -254,6 +254,12 @@ class StylizerNet:
                 need = ops.conv_to3_absorb_norm_ws_bytes(shape, nb.k, self.dtype)
                 if need == 0:
                     continue
+            elif nb.kind == 'deconv':                                  # the up-sampling kernel
+                if nb.tile_stats is None:
+                    continue
+                need = ops.conv_transpose_absorb_norm_ws_bytes(shape, nb.kshape, nb.s, self.dtype)
+                if need == 0:
+                    continue
             else:
                 if nb.kind != 'conv' or nb.rows is not None or nb.k != 3 or nb.tile_stats is None:
                     continue
@@ -320,7 +326,12 @@ class StylizerNet:
                 free = [p for p in self._pool if p.data_ptr() not in
                         (cur.data_ptr(), None if skip is None else skip.data_ptr())]
                 conv_out, y = self._view(free[0], b), self._view(free[1], b)
-            if b.kind == 'deconv':
+            if b.kind == 'deconv' and absorbed is not None:
+                ops.conv2d_transpose_fwd_absorb_norm(cur, absorbed.tile_stats, absorbed.scale, absorbed.shift, b.wp_fwd,
+                                                     b.kshape, b.s, b.tile_stats, absorbed.absorb_ws, in_stats=absorbed.stats,
+                                                     out=conv_out)
+                absorbed = None
+            elif b.kind == 'deconv':
                 ops.conv2d_transpose_fwd(cur, b.wp_fwd, b.kshape, b.s, out=conv_out, tile_stats=b.tile_stats)
             elif b.rgb and u8_in:
                 ops.conv2d_rgb_u8_fwd(x_f32, b.wp_fwd, b.k, b.co, self.dtype, out=conv_out, tile_stats=b.tile_stats)

@@ -449,7 +449,7 @@ def test_absorbed_norms_equal_the_apply_passes(cuda, monkeypatch):
     net = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)
     absorbing = [i for i, b in enumerate(net.blocks) if b.absorb_ws is not None]
     # the two layers in front of the down-sampling convolutions and the first layer of each residual block
-    assert absorbing == [0, 1, 3, 5, 7, 9, 11, 14] and all(net.blocks[i].role == 'a' for i in absorbing[2:7])
+    assert absorbing == [0, 1, 3, 5, 7, 9, 11, 13, 14] and all(net.blocks[i].role == 'a' for i in absorbing[2:7])
     out = net.forward(frames).clone()
     monkeypatch.setattr(tuning, 'ABSORB_NORM', False)
     plain = StylizerNet(2, 1024, 1536, cuda, torch.bfloat16, params=params)

@@ -265,6 +265,46 @@ def test_output_layer_absorbing_the_norm_in_front_of_it(cuda, case):
     assert rel_err(zr, ref) <= TOL[dtype]
 
 
+@pytest.mark.parametrize('case', [(2, 16, 64), (1, 13, 45), (1, 3, 2)], ids=lambda c: 'x'.join(map(str, c)))
+def test_transposed_convolution_absorbing_the_norm_in_front_of_it(cuda, case):
+    """full_graph_stylizer_network.py:72-76 at inference: the second up-sampling block's transposed convolution
+    reading the raw output of the first and applying that block's norm + ReLU on the way in; the four output classes
+    use different taps of the kernel, so each starts from the constant terms of its own taps."""
+    from stmi import ops
+    n, h, w = case
+    dtype, ci, co, k, s = torch.bfloat16, 64, 32, 3, 2
+    xa64 = rnd((n, h, w, ci), 1) * 0.8 + 0.3
+    wt = rnd((k, k, co, ci), 3, 1.0 / np.sqrt(k * k * ci))          # HWOI
+    sa, ha = rnd((ci,), 4).abs() + 0.5, rnd((ci,), 5)
+    sb, hb = rnd((co,), 6) + 1.5, rnd((co,), 7)
+    xa = xa64.to(cuda, dtype)
+    wp = ops.pack_conv_weights(wt.to(cuda, torch.float32), ops.PACK_DGRAD, dtype)
+    sad, had, sbd, hbd = (t.to(cuda, torch.float32) for t in (sa, ha, sb, hb))
+    ks = (k, k, co, ci)
+    need = ops.conv_transpose_absorb_norm_ws_bytes((n, h, w, ci), ks, s, dtype)
+    assert need > 0 and ops.conv_transpose_absorb_norm_ws_bytes((n, h, w, ci), ks, s, torch.float32) == 0
+    xf = xa.float()
+    k0 = xf[:, 0, 0, :]
+    d = xf - k0[:, None, None, :]
+    tiles_a = torch.stack([k0, d.sum(dim=(1, 2)), (d * d).sum(dim=(1, 2)), torch.full_like(k0, float(h * w))], dim=1)[:, None].contiguous()
+    ya, st_ref = ops.instance_norm_fwd(xa, sad, had, ops.ACT_RELU)
+    ts = ops.conv_transpose_tile_stats_tiles((n, h, w, ci), ks, s, dtype)
+    tiles_r = torch.zeros((n, ts, 4, co), device=cuda)
+    zr = ops.conv2d_transpose_fwd(ya, wp, ks, s, tile_stats=tiles_r)
+    tiles_b = torch.full((n, ts, 4, co), float('nan'), device=cuda)
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+    z, st = ops.conv2d_transpose_fwd_absorb_norm(xa, tiles_a, sad, had, wp, ks, s, tiles_b, ws)
+    assert 'conv_up2_clamp_kernel<__bf16, 1, 2>' in ops.last_conv_kernel()
+    assert rel_err(st[..., 1], st_ref[..., 1].double()) <= 1e-4
+    assert rel_err(z, zr.double()) <= 3e-2
+    out, _ = ops.instance_norm_fwd(z, sbd, hbd, ops.ACT_RELU, tile_stats=tiles_b)
+    y64 = torch.relu(O.instance_norm(q(xa64, dtype), sa.float().double(), ha.float().double()))
+    z_ref = O.conv2d_transpose_same(y64, q(wt, dtype), s)
+    assert rel_err(z, z_ref) <= TOL[dtype]
+    ref = torch.relu(O.instance_norm(z_ref, sb.float().double(), hb.float().double()))
+    assert rel_err(out, ref) <= TOL[dtype]
+
+
 KSPLIT_CASES = [
     # n, h, w, ci, co, forced slices (None: the planner's own choice, which must be a split)
     (4, 16, 16, 512, 512, None),     # VGG conv5_x of a training batch
