@@ -32,11 +32,11 @@ def demangled(name):
     if name.startswith('void stmi::conv_rgb_kernel<bool _Accum'):  # the profiler's own rendering of <__bf16, 9, 2, __bf16>
         return ('void stmi::conv_rgb_kernel<__bf16, 9, 2, __bf16>(__bf16 const*, float, float const*, __bf16 const*, '
                 'stmi::ConvGemmParams)')
-    m = re.match(r'_ZN4stmi15conv_to3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEEv', name)
+    m = re.match(r'_ZN4stmi15conv_to3_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])EEEv', name)
     if m:
         a = t(m.group(1))
-        return ('void stmi::conv_to3_kernel<%s, %s, %s, %s>(%s const*, %s const*, %s const*, %s*, int, int, int)'
-                % (a, m.group(2), m.group(3), m.group(4), a, a, a, a))
+        return ('void stmi::conv_to3_kernel<%s, %s, %s, %s, %s>(%s const*, %s const*, %s const*, %s*, int, int, int, stmi::To3Clamp)'
+                % (a, m.group(2), m.group(3), m.group(4), 'true' if m.group(5) == '1' else 'false', a, a, a, a))
     m = re.match(r'_ZN4stmi\d+(\w+?)I(DF16b|f)((?:Li\d+E)+)((?:Lb[01]E)*)EEvNS_\d+\w+E', name)
     if not m:
         # the profiler's own demangler renders "__bf16, 1" (DF16bLi1E) as "bool _Accum, int, E"
