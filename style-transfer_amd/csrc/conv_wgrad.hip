@@ -311,26 +311,30 @@ static int launch_wg_typed(const WgradParams& p, hipStream_t s) {
 static thread_local char g_last_wgrad[64] = "";
 const char* last_wgrad_kernel() { return g_last_wgrad; }
 
-// plans the launch (which kernel, how many pixel slices per tile); *ws_floats: the workspace it needs
-static bool plan_wgrad(WgradParams& p, int dtype, long* ws_floats) {
+// plans the launch (which kernel: 2 resident-patch, 1 LDS-DMA, 0 register-staged; how many pixel slices per tile);
+// *ws_floats: the workspace it needs
+static int plan_wgrad(WgradParams& p, int dtype, long* ws_floats) {
     WgPlan plan;
-    const bool glds = wgrad_glds_plan(p, dtype, &plan);
-    if (!glds) plan = reg_plan(p, dtype);
+    int kind = 0;
+    if (wgrad_res_plan(p, dtype, &plan)) kind = 2;
+    else if (wgrad_glds_plan(p, dtype, &plan)) kind = 1;
+    else plan = reg_plan(p, dtype);
     p.splits = plan.splits;
     p.pix_per_block = plan.pix_per_block;
     *ws_floats = plan.splits > 1 ? (long)plan.splits * p.out_elems : 0;
-    return glds;
+    return kind;
 }
 
 static int run_wgrad(WgradParams& p, int dtype, hipStream_t s, const char* who) {
     long need = 0;
     // the LDS-DMA kernel wants 16-byte aligned planes: plan with the workspace the call will really use
-    const bool glds = plan_wgrad(p, dtype, &need);
+    const int kind = plan_wgrad(p, dtype, &need);
     STMI_REQUIRE(need == 0 || p.ws, "%s: this geometry cuts every output tile into %d pixel slices and needs a "
                  "workspace of %ld floats (see the *_ws_floats query)", who, p.splits, need);
-    snprintf(g_last_wgrad, sizeof(g_last_wgrad), "%s", glds ? "wgrad_glds_kernel" : "wgrad_kernel");
-    int rc = glds ? launch_wgrad_glds(p, dtype, s)
-                  : (dtype == STMI_BF16 ? launch_wg_typed<bf16_t>(p, s) : launch_wg_typed<float>(p, s));
+    snprintf(g_last_wgrad, sizeof(g_last_wgrad), "%s", kind == 2 ? "wgrad_res_kernel" : kind == 1 ? "wgrad_glds_kernel" : "wgrad_kernel");
+    int rc = kind == 2 ? launch_wgrad_res(p, s)
+             : kind == 1 ? launch_wgrad_glds(p, dtype, s)
+                         : (dtype == STMI_BF16 ? launch_wg_typed<bf16_t>(p, s) : launch_wg_typed<float>(p, s));
     if (rc) return rc;
     return p.splits > 1 ? fold_partials(p, s) : STMI_OK;
 }

@@ -163,6 +163,28 @@ def test_training_is_bit_reproducible(cuda, dtype):
             assert torch.equal(a, b)
 
 
+def test_training_step_with_resident_patch_weight_gradients(cuda, monkeypatch):
+    """The residual layers' weight gradients from the resident-patch kernel (chosen by itself on large crops, asked
+    for here) inside a whole training step: the same gradients as with the tap-per-block kernel up to the order of
+    fp32 additions, and bit-reproducible."""
+    from stmi import ops
+    from stmi.trainer import StyleTrainer
+    batch, style, params, vggw, mean = small_setup(h=64, w=128)    # residual layers on 16 x 32 pixel planes
+    grads = []
+    for min_pix in ('0', '0', '1000000000'):
+        monkeypatch.setenv('STMI_WG_RES_MIN_PIX', min_pix)
+        tr = StyleTrainer(batch.shape[0], 64, 128, cuda, vggw, mean, 1e-2, 1e4, 1e8, dtype=torch.bfloat16, params=params,
+                          use_graph=False)
+        tr.set_style_image(torch.tensor(style))
+        tr.step(torch.tensor(batch, device=cuda))
+        torch.cuda.synchronize()
+        grads.append(tr.net.flat_grad.clone())
+        del tr
+    assert torch.equal(grads[0], grads[1])
+    assert not torch.equal(grads[0], grads[2]), 'both runs took the same kernel'
+    assert (grads[0] - grads[2]).abs().max() <= 1e-4 * grads[2].abs().max()
+
+
 def test_training_step_bf16_tracks_oracle(cuda):
     from stmi.trainer import StyleTrainer
     batch, style, params, vggw, mean = small_setup(h=64, w=48)
