@@ -8,7 +8,7 @@ os.environ['STMI_ENV_LIVE'] = '1'
 os.environ['STMI_WG_RES_MIN_PIX'] = '0'   # both kernels at every size
 from stmi import ops
 dev = torch.device('cuda:0')
-dtype = torch.bfloat16
+dtype = torch.float32 if os.environ.get('F32') else torch.bfloat16
 
 
 def timed(fn, n=20):

@@ -332,7 +332,7 @@ static int run_wgrad(WgradParams& p, int dtype, hipStream_t s, const char* who) 
     STMI_REQUIRE(need == 0 || p.ws, "%s: this geometry cuts every output tile into %d pixel slices and needs a "
                  "workspace of %ld floats (see the *_ws_floats query)", who, p.splits, need);
     snprintf(g_last_wgrad, sizeof(g_last_wgrad), "%s", kind == 2 ? "wgrad_res_kernel" : kind == 1 ? "wgrad_glds_kernel" : "wgrad_kernel");
-    int rc = kind == 2 ? launch_wgrad_res(p, s)
+    int rc = kind == 2 ? launch_wgrad_res(p, dtype, s)
              : kind == 1 ? launch_wgrad_glds(p, dtype, s)
                          : (dtype == STMI_BF16 ? launch_wg_typed<bf16_t>(p, s) : launch_wg_typed<float>(p, s));
     if (rc) return rc;

@@ -38,9 +38,9 @@ struct WgPlan {
 bool wgrad_glds_plan(const WgradParams& p, int dtype, WgPlan* plan);
 int launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s);
 
-// Resident-patch variant for 3x3 stride-1 layers in bf16 (conv_wgrad_res.hip): a block owns a 32 x 32 tile under all
+// Resident-patch variant for 3x3 stride-1 layers (conv_wgrad_res.hip): a block owns a 32 x 32 tile under all
 // nine taps and a slice of whole image rows.  wgrad_res_plan returns false when the problem does not fit it.
 bool wgrad_res_plan(const WgradParams& p, int dtype, WgPlan* plan);
-int launch_wgrad_res(const WgradParams& p, hipStream_t s);
+int launch_wgrad_res(const WgradParams& p, int dtype, hipStream_t s);
 
 }  // namespace stmi

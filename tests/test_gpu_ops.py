@@ -1015,7 +1015,8 @@ def test_wgrad_and_gram_pixel_slices_fold_in_fixed_order(cuda, dtype, chans):
 
 @pytest.mark.parametrize('case', [(4, 64, 64, 128, 128), (2, 8, 32, 32, 64), (3, 6, 128, 64, 32), (2, 3, 256, 32, 32), (2, 5, 64, 32, 32),
                                   (1, 4, 96, 96, 32)], ids=lambda c: 'x'.join(map(str, c)))
-def test_wgrad_with_the_patch_resident(cuda, case, monkeypatch):
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_wgrad_with_the_patch_resident(cuda, case, dtype, monkeypatch):
     """3x3 stride-1 weight gradients in bf16 on rows that are multiples of 32 pixels (the residual layers of
     full_graph_stylizer_network.py:52-57 on large training crops): a block keeps the rows' halo patch in LDS and
     reads it under all nine taps.  Against the fp64 oracle, the same bits on every run; `accumulate`; samples whose
@@ -1023,13 +1024,13 @@ def test_wgrad_with_the_patch_resident(cuda, case, monkeypatch):
     from stmi import ops
     monkeypatch.setenv('STMI_WG_RES_MIN_PIX', '0')
     n, h, w, ci, co = case
-    dtype = torch.bfloat16
     x, dy = rnd((n, h, w, ci), 1), rnd((n, h, w, co), 2)
     wz = torch.zeros((3, 3, ci, co), dtype=torch.float64, requires_grad=True)
     (gw_ref,) = torch.autograd.grad(O.conv2d_same(q(x, dtype), wz, 1), wz, q(dy, dtype))
     xd, dyd = x.to(cuda, dtype), dy.to(cuda, dtype)
     first = ops.conv2d_wgrad(xd, dyd, (3, 3, ci, co), 1)
-    assert ops.last_wgrad_kernel() == 'wgrad_res_kernel'
+    # (an fp32 row of 256 pixels with its halo is more than the LDS buffers hold)
+    assert ops.last_wgrad_kernel() == ('wgrad_glds_kernel' if dtype == torch.float32 and w > 128 else 'wgrad_res_kernel')
     assert rel_err(first, gw_ref) <= TOL[dtype]
     for _ in range(3):
         assert torch.equal(ops.conv2d_wgrad(xd, dyd, (3, 3, ci, co), 1), first)
@@ -1041,8 +1042,8 @@ def test_wgrad_with_the_patch_resident(cuda, case, monkeypatch):
 
 
 def test_wgrad_patch_resident_falls_back(cuda):
-    """Rows too long for the LDS or not multiples of 32 pixels, fp32 and strided layers keep the tap-per-block
-    kernel, and so do small problems unless asked; large ones take the resident-patch kernel by themselves."""
+    """Rows too long for the LDS or not multiples of 32 pixels and strided layers keep the tap-per-block kernel, and
+    so do small bf16 problems unless asked; large ones, and fp32 ones of any size, take the resident-patch kernel."""
     from stmi import ops
     xs, dys = rnd((4, 64, 64, 32), 1).to(cuda, torch.bfloat16), rnd((4, 64, 64, 32), 2).to(cuda, torch.bfloat16)
     small = ops.conv2d_wgrad(xs, dys, (3, 3, 32, 32), 1)
@@ -1051,8 +1052,10 @@ def test_wgrad_patch_resident_falls_back(cuda):
     large = ops.conv2d_wgrad(xl, dyl, (3, 3, 32, 32), 1)
     assert ops.last_wgrad_kernel() == 'wgrad_res_kernel'
     assert rel_err(large, 2 * small) <= TOL[torch.bfloat16]
+    ops.conv2d_wgrad(xs.float(), dys.float(), (3, 3, 32, 32), 1)
+    assert ops.last_wgrad_kernel() == 'wgrad_res_kernel'
     for (n, h, w, ci, co, s, dtype) in [(32, 4, 288, 32, 32, 1, torch.bfloat16), (16, 64, 36, 32, 32, 1, torch.bfloat16),
-                                        (8, 64, 64, 32, 32, 1, torch.float32), (8, 128, 64, 32, 32, 2, torch.bfloat16)]:
+                                        (8, 64, 36, 32, 32, 1, torch.float32), (8, 128, 64, 32, 32, 2, torch.bfloat16)]:
         x = rnd((n, h, w, ci), 1).to(cuda, dtype)
         dy = rnd((n, (h + s - 1) // s, (w + s - 1) // s, co), 2).to(cuda, dtype)
         wz = torch.zeros((3, 3, ci, co), dtype=torch.float64, requires_grad=True)
