@@ -44,7 +44,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // chunk swizzle of a tile with RB-byte rows (conflict-free ds_read_b64_tr_b16 fragment reads)
 template <int RB>
 __device__ __forceinline__ int row_swz(int r) {
-    return RB == 128 ? ((r >> 1) & 3) << 1 : ((r >> 2) & 1) << 1;
+    // 256-byte rows (fp32 tiles of 64 channels, four-byte reads): the four rows a read touches go to four
+    // different 64-byte groups
+    return RB == 256 ? (r & 3) << 2 : RB == 128 ? ((r >> 1) & 3) << 1 : ((r >> 2) & 1) << 1;
 }
 
 // fragment of 16 channels (col0..) x one K group of pixels (row0..) from a swizzled tile
@@ -85,7 +87,7 @@ template <int RB> struct TileFrag<float, RB> {
     }
 };
 
-constexpr int kStepPix = 128;  // pixel rows per ring slot and operand
+constexpr int kStepPix = 128;  // pixel rows per ring slot and operand (64 for the 256-byte rows of fp32)
 constexpr int kRing = 4;
 constexpr int kProducers = 8;  // DMA-issuing waves: the fill rate of a CU scales with the waves that issue
 constexpr int kThreads = 64 * (4 + kProducers);
@@ -93,8 +95,9 @@ constexpr int kThreads = 64 * (4 + kProducers);
 }  // namespace
 
 // XB / DB: bytes per pixel row of the X / DY tile (128 or 64: 64 or 32 bf16 channels)
-template <typename T, int XB, int DB>
+template <typename T, int XB, int DB, int SP = kStepPix>
 __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams p) {
+    constexpr int kStepPix = SP;   // (shadows the default: everything below counts in this launch's steps)
     constexpr int EPC = 16 / sizeof(T);
     constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);  // tile: TE x-channels by TD dy-channels
     constexpr int TWX = TE / 32, TWD = TD / 32;  // 16-channel fragments per consumer wave (2 x 2 waves)
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_glds_kernel(const WgradParams 
 // bytes per tile row for a channel count, 0 when the kernel cannot take it
 static int row_bytes(int channels, int dtype) {
     const int es = dtype == STMI_BF16 ? 2 : 4;
+    // fp32: 64 channels a row where both operands have them (tile_dims): twice the products per byte of fill of
+    // the 32-channel tiles, and the fill is what bounds these launches
+    if (dtype != STMI_BF16 && channels * es % 256 == 0 && !STMI_ENV_SET("STMI_NO_WG_F32_WIDE")) return 256;
     if (channels * es % 128 == 0) return 128;
     if (dtype == STMI_BF16 && channels * es % 64 == 0) return 64;  // 32 bf16 channels; f32 tiles would be too narrow
     return 0;
@@ -325,10 +331,19 @@ static WgPlan plan_for(const WgradParams& p, int te, int td) {
     return plan;
 }
 
+// bytes per tile row of the two operands: bf16 128 or 64 each; fp32 256 for both where both have 64 channels, else 128
+static void tile_row_bytes(const WgradParams& p, int dtype, int* xb, int* db) {
+    *xb = row_bytes(p.Ci, dtype);
+    *db = row_bytes(p.Co, dtype);
+    if (dtype != STMI_BF16 && (*xb != 256 || *db != 256)) *xb = *db = 128;
+}
+
 static void tile_dims(const WgradParams& p, int dtype, int* te, int* td) {
     const int es = dtype == STMI_BF16 ? 2 : 4;
-    *te = (dtype == STMI_BF16 ? row_bytes(p.Ci, dtype) : 128) / es;
-    *td = (dtype == STMI_BF16 ? row_bytes(p.Co, dtype) : 128) / es;
+    int xb, db;
+    tile_row_bytes(p, dtype, &xb, &db);
+    *te = xb / es;
+    *td = db / es;
 }
 
 bool wgrad_glds_plan(const WgradParams& p, int dtype, WgPlan* plan) {
@@ -339,25 +354,27 @@ bool wgrad_glds_plan(const WgradParams& p, int dtype, WgPlan* plan) {
     return true;
 }
 
-template <typename T, int XB, int DB>
+template <typename T, int XB, int DB, int SP = kStepPix>
 static int launch_wg_glds(const WgradParams& p, hipStream_t s) {
     constexpr int TE = XB / (int)sizeof(T), TD = DB / (int)sizeof(T);
-    constexpr size_t kLds = (size_t)kRing * kStepPix * (XB + DB);
-    STMI_DYN_LDS((wgrad_glds_kernel<T, XB, DB>), (int)kLds, "hipFuncSetAttribute(wgrad_glds_kernel)");
+    constexpr size_t kLds = (size_t)kRing * SP * (XB + DB);
+    static_assert(kLds <= 160 * 1024, "the ring exceeds the CU's LDS");
+    STMI_DYN_LDS((wgrad_glds_kernel<T, XB, DB, SP>), (int)kLds, "hipFuncSetAttribute(wgrad_glds_kernel)");
     const bool batched = p.batch_out_stride != 0;
     const long tiles = (long)p.ntaps * (p.klen / TE) * (p.Co / TD);
     const long blocks = tiles * p.splits * (batched ? p.N : 1);
     STMI_REQUIRE(blocks < (1L << 31), "wgrad: grid too large");
     STMI_REQUIRE(p.splits == 1 || p.ws, "wgrad: %d pixel slices per tile need the workspace", p.splits);
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL((wgrad_glds_kernel<T, XB, DB>), grid, dim3(kThreads), kLds, s, p);
+    hipLaunchKernelGGL((wgrad_glds_kernel<T, XB, DB, SP>), grid, dim3(kThreads), kLds, s, p);
     STMI_LAUNCH_CHECK("wgrad_glds_kernel");
     return STMI_OK;
 }
 
 int launch_wgrad_glds(const WgradParams& p, int dtype, hipStream_t s) {
-    const int xb = row_bytes(p.Ci, dtype), db = row_bytes(p.Co, dtype);
-    if (dtype != STMI_BF16) return launch_wg_glds<float, 128, 128>(p, s);
+    int xb, db;
+    tile_row_bytes(p, dtype, &xb, &db);
+    if (dtype != STMI_BF16) return xb == 256 ? launch_wg_glds<float, 256, 256, 64>(p, s) : launch_wg_glds<float, 128, 128>(p, s);
     if (xb == 128) return db == 128 ? launch_wg_glds<bf16_t, 128, 128>(p, s) : launch_wg_glds<bf16_t, 128, 64>(p, s);
     return db == 128 ? launch_wg_glds<bf16_t, 64, 128>(p, s) : launch_wg_glds<bf16_t, 64, 64>(p, s);
 }
